@@ -1,0 +1,98 @@
+/* lungmask_hip.h -- C ABI of liblungmask_hip.so, the MI355X (gfx950) engine that
+ * replaces the hot path of JoHof/lungmask: `LMInferer.apply()` ->
+ * `LMInferer._inference()` (reference lungmask/mask.py:141-232) and everything
+ * it calls in lungmask/resunet.py and lungmask/utils.py.
+ *
+ * The reference has no FFI seam (it is pure Python over torch/scipy/skimage);
+ * the entry points below are what a ctypes binding inside the reference's
+ * `mask.py` / `utils.py` would call -- one per reference call site, cited on
+ * each declaration.  INTEGRATION.md shows that binding.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes only; no torch / numpy types.
+ *   - every function returns 0 on success or a negative lm_status; the message
+ *     is available from lm_last_error() (thread-local).
+ *   - "dev" pointers are HBM addresses (hipMalloc / torch.cuda tensors /
+ *     lm_dev_alloc); "host" pointers are ordinary memory.
+ *   - an lm_engine owns one device, one HIP stream and its workspaces; it is not
+ *     thread-safe, distinct engines are independent.
+ *   - volumes are C-contiguous [n][h][w]; labels are uint8.
+ */
+#ifndef LUNGMASK_HIP_H
+#define LUNGMASK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lm_engine lm_engine;
+
+typedef enum lm_status {
+    LM_OK = 0,
+    LM_ERR_INVALID = -1,  /* bad argument / shape / state            */
+    LM_ERR_DEVICE = -2,   /* HIP runtime error (message has details) */
+    LM_ERR_NOMODEL = -3,  /* model slot empty                        */
+    LM_ERR_ALLOC = -4
+} lm_status;
+
+/* dtype codes for input volumes (numpy mode of mask.py:153-155 accepts any dtype) */
+enum { LM_I16 = 0, LM_I32 = 1, LM_F32 = 2, LM_F64 = 3, LM_U8 = 4, LM_U16 = 5, LM_I64 = 6 };
+
+/* One named tensor of a torch state_dict (fp32, C-contiguous, host memory). */
+typedef struct lm_tensor {
+    const char* name; /* e.g. "down_path.0.block.0.weight" */
+    const float* data;
+    int64_t numel;
+} lm_tensor;
+
+/* ---- lifetime ---------------------------------------------------------------- */
+const char* lm_last_error(void);
+const char* lm_version(void);
+/* 1 if the library was built for the GPU (always, for the shipped library). */
+int lm_is_gpu_build(void);
+/* mask.py:118-134 (device selection) -> explicit device ordinal. */
+int lm_engine_create(lm_engine** out, int device_id);
+void lm_engine_destroy(lm_engine* e);
+int lm_engine_sync(lm_engine* e);
+
+/* ---- device memory helpers (so a binding needs no other GPU runtime) ---------- */
+int lm_dev_alloc(lm_engine* e, void** dev_ptr, size_t bytes);
+int lm_dev_free(lm_engine* e, void* dev_ptr);
+int lm_copy_h2d(lm_engine* e, void* dev_dst, const void* host_src, size_t bytes);
+int lm_copy_d2h(lm_engine* e, void* host_dst, const void* dev_src, size_t bytes);
+
+/* ---- model (mask.py:38-68 get_model) ------------------------------------------ */
+/* Loads a U-Net state_dict into `slot` (0..3).  n_classes is taken from
+ * "last.bias" exactly as mask.py:56 does; the always-present-but-unused
+ * residual_* tensors and num_batches_tracked are accepted and ignored. */
+int lm_model_load(lm_engine* e, int slot, const lm_tensor* tensors, int n_tensors);
+int lm_model_classes(lm_engine* e, int slot);
+
+/* ---- network forward (mask.py:178-186: model(mbt) + torch.max(pred,1)[1]) ------ */
+/* x_dev: f32 [b][h][w] (h, w multiples of 16).  labels_dev: u8 [b][h][w] or NULL.
+ * logp_dev: f32 [b][C][h][w] log-softmax exactly like UNet.forward's return
+ * (resunet.py:70), or NULL. */
+int lm_forward_dev(lm_engine* e, int slot, const float* x_dev, int b, int h, int w,
+                   uint8_t* labels_dev, float* logp_dev);
+
+/* Per-kernel timing of the network launches since the last reset (HIP events on
+ * the engine stream; enabled with lm_profile_enable(e, 1)).  Returns the number
+ * of distinct kernel kinds; fills up to `cap` entries. */
+typedef struct lm_kernel_stat {
+    char name[48];
+    int64_t launches;
+    double total_ms;
+    double flops; /* algorithmic FLOPs of those launches (0 for non-GEMM kernels) */
+    double bytes; /* algorithmic HBM bytes of those launches */
+} lm_kernel_stat;
+int lm_profile_enable(lm_engine* e, int on);
+int lm_profile_reset(lm_engine* e);
+int lm_profile_read(lm_engine* e, lm_kernel_stat* out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LUNGMASK_HIP_H */

@@ -1,0 +1,220 @@
+"""ctypes binding of liblungmask_hip.so (include/lungmask_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or no GPU is
+visible, `load()` / `Engine()` raise.  (`tests/` may point `Library` at the
+g++-built emulation of the same kernel sources; that library reports
+`lm_is_gpu_build() == 0` and is refused here unless explicitly allowed.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(HERE, "liblungmask_hip.so")
+
+LM_DTYPES = {
+    np.dtype(np.int16): 0,
+    np.dtype(np.int32): 1,
+    np.dtype(np.float32): 2,
+    np.dtype(np.float64): 3,
+    np.dtype(np.uint8): 4,
+    np.dtype(np.uint16): 5,
+    np.dtype(np.int64): 6,
+}
+
+
+class LMError(RuntimeError):
+    pass
+
+
+class _Tensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.POINTER(C.c_float)), ("numel", C.c_int64)]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+class Library:
+    def __init__(self, path: Optional[str] = None, allow_emulation: bool = False):
+        path = path or os.environ.get("LUNGMASK_HIP_LIB") or DEFAULT_LIB
+        if not os.path.exists(path):
+            raise LMError(
+                f"{path} not found: build it with `python -m lungmask_amd.build` (hipcc, gfx950). "
+                "lungmask_amd has no CPU fallback."
+            )
+        self.path = path
+        self.lib = C.CDLL(path)
+        L = self.lib
+        L.lm_last_error.restype = C.c_char_p
+        L.lm_version.restype = C.c_char_p
+        L.lm_engine_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        L.lm_engine_destroy.argtypes = [C.c_void_p]
+        L.lm_engine_destroy.restype = None
+        L.lm_engine_sync.argtypes = [C.c_void_p]
+        L.lm_dev_alloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]
+        L.lm_dev_free.argtypes = [C.c_void_p, C.c_void_p]
+        L.lm_copy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.lm_copy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.lm_model_load.argtypes = [C.c_void_p, C.c_int, C.POINTER(_Tensor), C.c_int]
+        L.lm_model_classes.argtypes = [C.c_void_p, C.c_int]
+        L.lm_forward_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.lm_profile_enable.argtypes = [C.c_void_p, C.c_int]
+        L.lm_profile_reset.argtypes = [C.c_void_p]
+        L.lm_profile_read.argtypes = [C.c_void_p, C.POINTER(KernelStat), C.c_int]
+        self.is_gpu = bool(L.lm_is_gpu_build())
+        if not self.is_gpu and not allow_emulation:
+            raise LMError(f"{path} is not a GPU build; refusing to run the product path on an emulation library")
+
+    def check(self, status: int, what: str = ""):
+        if status < 0:
+            raise LMError(f"{what or 'lungmask_hip'} failed ({status}): {self.lib.lm_last_error().decode()}")
+        return status
+
+
+_default: Optional[Library] = None
+
+
+def load() -> Library:
+    global _default
+    if _default is None:
+        _default = Library()
+    return _default
+
+
+class DeviceArray:
+    """A typed device allocation owned by an Engine (freed with it or via free())."""
+
+    def __init__(self, eng: "Engine", shape, dtype):
+        self.eng = eng
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = C.c_void_p()
+        eng.L.check(eng.L.lib.lm_dev_alloc(eng.h, C.byref(p), self.nbytes), "lm_dev_alloc")
+        self.ptr = p.value
+
+    def upload(self, arr: np.ndarray) -> "DeviceArray":
+        a = np.ascontiguousarray(arr, dtype=self.dtype)
+        assert a.nbytes == self.nbytes, (a.shape, self.shape)
+        self.eng.L.check(self.eng.L.lib.lm_copy_h2d(self.eng.h, self.ptr, a.ctypes.data, self.nbytes), "lm_copy_h2d")
+        return self
+
+    def download(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=self.dtype)
+        self.eng.L.check(self.eng.L.lib.lm_copy_d2h(self.eng.h, out.ctypes.data, self.ptr, self.nbytes), "lm_copy_d2h")
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.eng.L.lib.lm_dev_free(self.eng.h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            if self.ptr and self.eng.h:
+                self.free()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One device + one HIP stream + workspaces (lm_engine)."""
+
+    def __init__(self, device_id: int = 0, library: Optional[Library] = None):
+        self.L = library or load()
+        h = C.c_void_p()
+        self.L.check(self.L.lib.lm_engine_create(C.byref(h), device_id), "lm_engine_create")
+        self.h = h.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lib.lm_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- memory
+    def empty(self, shape, dtype) -> DeviceArray:
+        return DeviceArray(self, shape, dtype)
+
+    def to_device(self, arr: np.ndarray) -> DeviceArray:
+        arr = np.ascontiguousarray(arr)
+        return DeviceArray(self, arr.shape, arr.dtype).upload(arr)
+
+    def sync(self):
+        self.L.check(self.L.lib.lm_engine_sync(self.h), "lm_engine_sync")
+
+    # -- model
+    def load_state_dict(self, slot: int, state_dict: Dict[str, "np.ndarray"]) -> int:
+        """state_dict: name -> array-like (torch tensors are converted with .numpy())."""
+        keep, names, arrs = [], [], []
+        for k, v in state_dict.items():
+            if hasattr(v, "detach"):
+                v = v.detach().cpu().numpy()
+            a = np.asarray(v)
+            if a.dtype.kind != "f":
+                continue  # num_batches_tracked
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            names.append(k.encode())
+            arrs.append(a)
+        tens = (_Tensor * len(arrs))()
+        for i, (n, a) in enumerate(zip(names, arrs)):
+            tens[i].name = n
+            tens[i].data = a.ctypes.data_as(C.POINTER(C.c_float))
+            tens[i].numel = a.size
+        keep.append((names, arrs))
+        self.L.check(self.L.lib.lm_model_load(self.h, slot, tens, len(arrs)), "lm_model_load")
+        return self.L.check(self.L.lib.lm_model_classes(self.h, slot))
+
+    def n_classes(self, slot: int) -> int:
+        return self.L.check(self.L.lib.lm_model_classes(self.h, slot), "lm_model_classes")
+
+    # -- network
+    def forward_dev(self, slot: int, x: DeviceArray, labels: Optional[DeviceArray] = None, logp: Optional[DeviceArray] = None):
+        b, h, w = x.shape
+        self.L.check(
+            self.L.lib.lm_forward_dev(self.h, slot, x.ptr, b, h, w, labels.ptr if labels else None, logp.ptr if logp else None),
+            "lm_forward_dev",
+        )
+
+    def forward(self, slot: int, x: np.ndarray, want_logp: bool = True):
+        """x: f32 [b,h,w] (or [b,1,h,w]) host -> (labels u8 [b,h,w], logp f32 [b,C,h,w] or None)."""
+        x = np.asarray(x, dtype=np.float32)
+        if x.ndim == 4:
+            x = x[:, 0]
+        b, h, w = x.shape
+        c = self.n_classes(slot)
+        xd = self.to_device(x)
+        ld = self.empty((b, h, w), np.uint8)
+        pd = self.empty((b, c, h, w), np.float32) if want_logp else None
+        self.forward_dev(slot, xd, ld, pd)
+        self.sync()
+        out = ld.download(), (pd.download() if pd else None)
+        for d in (xd, ld, pd):
+            if d is not None:
+                d.free()
+        return out
+
+    # -- profiling
+    def profile(self, on: bool):
+        self.L.check(self.L.lib.lm_profile_enable(self.h, int(on)))
+
+    def profile_reset(self):
+        self.L.check(self.L.lib.lm_profile_reset(self.h))
+
+    def profile_read(self):
+        buf = (KernelStat * 32)()
+        n = self.L.check(self.L.lib.lm_profile_read(self.h, buf, 32))
+        return [
+            dict(name=buf[i].name.decode(), launches=buf[i].launches, total_ms=buf[i].total_ms, flops=buf[i].flops, bytes=buf[i].bytes)
+            for i in range(min(n, 32))
+        ]

@@ -1,0 +1,97 @@
+// Host-side engine state behind the C ABI (include/lungmask_hip.h).
+#pragma once
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/lungmask_hip.h"
+#include "lm_platform.h"
+#include "nn_kernels.h"
+
+namespace lm {
+
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+#define LM_HIP(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) {                                                                       \
+            lm::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return LM_ERR_DEVICE;                                                                     \
+        }                                                                                             \
+    } while (0)
+
+#define LM_TRY(expr)                \
+    do {                            \
+        int _s = (expr);            \
+        if (_s != LM_OK) return _s; \
+    } while (0)
+
+// Grow-only device buffer.
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct ConvLayer {
+    float *w = nullptr, *bias = nullptr, *bn_s = nullptr, *bn_t = nullptr;
+    int cin = 0, cout = 0, taps = 0;
+};
+
+struct Model {
+    bool loaded = false;
+    int n_classes = 0;
+    ConvLayer first;       // down_path.0.block.0 (Cin = 1)
+    ConvLayer down[5][2];  // [0][0] unused (== first)
+    ConvLayer up1x1[4];    // up_path.i.up.1
+    ConvLayer upc[4][2];   // up_path.i.conv_block.block.{0,3}
+    float *head_w = nullptr, *head_b = nullptr;
+    std::vector<void*> allocs;
+    void release();
+};
+
+// Per-launch HIP-event timing on the engine stream (feeds bench.py's roofline block).
+struct Profiler {
+    bool on = false;
+    struct Rec {
+        int kind;
+        hipEvent_t a, b;
+        double flops, bytes;
+    };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    std::vector<std::string> names;
+    std::map<int, lm_kernel_stat> acc;
+    int kind_id(const char* name);
+    hipEvent_t get_event();
+    void begin(hipStream_t s, int kind, double flops, double bytes);
+    void end(hipStream_t s);
+    void collect();
+    void reset();
+    void release();
+};
+
+struct NNWorkspace {
+    DevBuf t1, t2, t3, cat[4], pool[4];
+};
+
+}  // namespace lm
+
+struct lm_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    lm::Model models[4];
+    lm::NNWorkspace nn;
+    lm::Profiler prof;
+};
+
+namespace lm {
+int model_load(lm_engine* e, int slot, const lm_tensor* tensors, int n);
+int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t* labels, float* logp);
+}  // namespace lm

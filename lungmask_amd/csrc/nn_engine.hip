@@ -1,0 +1,339 @@
+// Model loading (mask.py:38-68) and the layer schedule of UNet.forward
+// (resunet.py:58-70) on top of the kernels in nn_kernels.hip.
+#include <cmath>
+#include <cstring>
+
+#include "engine.h"
+
+namespace lm {
+
+static thread_local std::string g_err;
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+const char* get_error() { return g_err.c_str(); }
+
+int DevBuf::reserve(size_t bytes) {
+    if (bytes <= cap) return LM_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t err = hipMalloc(&p, bytes);
+    if (err != hipSuccess) {
+        set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
+        return LM_ERR_ALLOC;
+    }
+    cap = bytes;
+    return LM_OK;
+}
+void DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+void Model::release() {
+    for (void* a : allocs) (void)hipFree(a);
+    allocs.clear();
+    loaded = false;
+}
+
+// ------------------------------------------------------------------------------ profiler
+int Profiler::kind_id(const char* name) {
+    for (size_t i = 0; i < names.size(); ++i)
+        if (names[i] == name) return (int)i;
+    names.push_back(name);
+    return (int)names.size() - 1;
+}
+hipEvent_t Profiler::get_event() {
+    if (!pool.empty()) {
+        hipEvent_t e = pool.back();
+        pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void Profiler::begin(hipStream_t s, int kind, double flops, double bytes) {
+    if (!on) return;
+    Rec r{kind, get_event(), get_event(), flops, bytes};
+    (void)hipEventRecord(r.a, s);
+    recs.push_back(r);
+}
+void Profiler::end(hipStream_t s) {
+    if (!on) return;
+    (void)hipEventRecord(recs.back().b, s);
+}
+void Profiler::collect() {
+    for (Rec& r : recs) {
+        (void)hipEventSynchronize(r.b);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        lm_kernel_stat& st = acc[r.kind];
+        if (st.launches == 0) {
+            memset(&st, 0, sizeof st);
+            strncpy(st.name, names[r.kind].c_str(), sizeof(st.name) - 1);
+        }
+        st.launches++;
+        st.total_ms += ms;
+        st.flops += r.flops;
+        st.bytes += r.bytes;
+        pool.push_back(r.a);
+        pool.push_back(r.b);
+    }
+    recs.clear();
+}
+void Profiler::reset() {
+    collect();
+    acc.clear();
+}
+void Profiler::release() {
+    collect();
+    for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+    pool.clear();
+}
+
+// ------------------------------------------------------------------------------ model loading
+namespace {
+
+struct TensorMap {
+    std::map<std::string, const lm_tensor*> m;
+    const lm_tensor* get(const std::string& name, int64_t numel) const {
+        auto it = m.find(name);
+        if (it == m.end()) {
+            set_error("state_dict is missing tensor '%s'", name.c_str());
+            return nullptr;
+        }
+        if (it->second->numel != numel) {
+            set_error("tensor '%s' has %lld elements, expected %lld", name.c_str(), (long long)it->second->numel, (long long)numel);
+            return nullptr;
+        }
+        return it->second;
+    }
+};
+
+int upload(Model& md, const std::vector<float>& host, float** dev) {
+    void* p = nullptr;
+    hipError_t err = hipMalloc(&p, host.size() * sizeof(float));
+    if (err != hipSuccess) {
+        set_error("hipMalloc for weights failed: %s", hipGetErrorString(err));
+        return LM_ERR_ALLOC;
+    }
+    md.allocs.push_back(p);
+    LM_HIP(hipMemcpy(p, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    *dev = reinterpret_cast<float*>(p);
+    return LM_OK;
+}
+
+// conv weight [cout][cin][kh][kw] -> [tap = kh*3+kw][cin][cout]; optional BatchNorm (eval) folded to
+// the per-channel affine y = x*s + t, s = gamma/sqrt(var+1e-5), t = beta - mean*s (applied AFTER ReLU,
+// resunet.py:97-100 -- it cannot be folded into the conv).
+int load_conv(Model& md, const TensorMap& tm, const std::string& conv, const std::string& bnp, int cin, int cout, int taps, ConvLayer* L) {
+    const lm_tensor* w = tm.get(conv + ".weight", (int64_t)cout * cin * taps);
+    const lm_tensor* b = tm.get(conv + ".bias", cout);
+    if (!w || !b) return LM_ERR_INVALID;
+    std::vector<float> pw((size_t)taps * cin * cout);
+    for (int o = 0; o < cout; ++o)
+        for (int i = 0; i < cin; ++i)
+            for (int t = 0; t < taps; ++t) pw[((size_t)t * cin + i) * cout + o] = w->data[((size_t)o * cin + i) * taps + t];
+    LM_TRY(upload(md, pw, &L->w));
+    LM_TRY(upload(md, std::vector<float>(b->data, b->data + cout), &L->bias));
+    if (!bnp.empty()) {
+        const lm_tensor* g = tm.get(bnp + ".weight", cout);
+        const lm_tensor* be = tm.get(bnp + ".bias", cout);
+        const lm_tensor* mu = tm.get(bnp + ".running_mean", cout);
+        const lm_tensor* var = tm.get(bnp + ".running_var", cout);
+        if (!g || !be || !mu || !var) return LM_ERR_INVALID;
+        std::vector<float> s(cout), t(cout);
+        for (int o = 0; o < cout; ++o) {
+            const double sd = (double)g->data[o] / std::sqrt((double)var->data[o] + 1e-5);
+            s[o] = (float)sd;
+            t[o] = (float)((double)be->data[o] - (double)mu->data[o] * sd);
+        }
+        LM_TRY(upload(md, s, &L->bn_s));
+        LM_TRY(upload(md, t, &L->bn_t));
+    }
+    L->cin = cin;
+    L->cout = cout;
+    L->taps = taps;
+    return LM_OK;
+}
+
+}  // namespace
+
+int model_load(lm_engine* e, int slot, const lm_tensor* tensors, int n) {
+    if (slot < 0 || slot >= 4 || !tensors || n <= 0) {
+        set_error("lm_model_load: bad slot/tensors");
+        return LM_ERR_INVALID;
+    }
+    Model& md = e->models[slot];
+    md.release();
+    TensorMap tm;
+    for (int i = 0; i < n; ++i)
+        if (tensors[i].name && tensors[i].data) tm.m[tensors[i].name] = &tensors[i];
+    auto it = tm.m.find("last.bias");
+    if (it == tm.m.end()) {
+        set_error("state_dict has no 'last.bias'");
+        return LM_ERR_INVALID;
+    }
+    const int C = (int)it->second->numel;  // mask.py:56
+    if (C < 1 || C > kMaxClasses) {
+        set_error("unsupported class count %d", C);
+        return LM_ERR_INVALID;
+    }
+    md.n_classes = C;
+    int prev = 1;
+    for (int i = 0; i < 5; ++i) {
+        const int co = 64 << i;
+        const std::string p = "down_path." + std::to_string(i) + ".block.";
+        if (i == 0)
+            LM_TRY(load_conv(md, tm, p + "0", p + "2", 1, co, 9, &md.first));
+        else
+            LM_TRY(load_conv(md, tm, p + "0", p + "2", prev, co, 9, &md.down[i][0]));
+        LM_TRY(load_conv(md, tm, p + "3", p + "5", co, co, 9, &md.down[i][1]));
+        prev = co;
+    }
+    for (int i = 0; i < 4; ++i) {
+        const int co = 512 >> i;
+        const std::string p = "up_path." + std::to_string(i);
+        LM_TRY(load_conv(md, tm, p + ".up.1", "", prev, co, 1, &md.up1x1[i]));
+        LM_TRY(load_conv(md, tm, p + ".conv_block.block.0", p + ".conv_block.block.2", prev, co, 9, &md.upc[i][0]));
+        LM_TRY(load_conv(md, tm, p + ".conv_block.block.3", p + ".conv_block.block.5", co, co, 9, &md.upc[i][1]));
+        prev = co;
+    }
+    const lm_tensor* hw = tm.get("last.weight", (int64_t)C * 64);
+    if (!hw) return LM_ERR_INVALID;
+    LM_TRY(upload(md, std::vector<float>(hw->data, hw->data + C * 64), &md.head_w));
+    LM_TRY(upload(md, std::vector<float>(it->second->data, it->second->data + C), &md.head_b));
+    md.loaded = true;
+    return LM_OK;
+}
+
+// ------------------------------------------------------------------------------ forward
+namespace {
+
+struct Fwd {
+    lm_engine* e;
+    int B;
+    int kc3, kc1, kfirst, kup, khead;
+
+    int conv(const ConvLayer& L, const float* in, int in_cs, int in_co, int H, int W, float* out, int out_cs, int out_co,
+             float* pool = nullptr, int pool_cs = 0, int pool_co = 0) {
+        ConvParams p{};
+        p.in = in;
+        p.in_cstride = in_cs;
+        p.in_coff = in_co;
+        p.w = L.w;
+        p.bias = L.bias;
+        p.bn_s = L.bn_s;
+        p.bn_t = L.bn_t;
+        p.out = out;
+        p.out_cstride = out_cs;
+        p.out_coff = out_co;
+        p.pool = pool;
+        p.pool_cstride = pool_cs;
+        p.pool_coff = pool_co;
+        p.B = B;
+        p.H = H;
+        p.W = W;
+        p.Cin = L.cin;
+        p.Cout = L.cout;
+        const double px = (double)B * H * W;
+        const double flops = 2.0 * px * L.cout * L.cin * L.taps;
+        const double bytes = 4.0 * (px * (L.cin + L.cout) + (pool ? px / 4 * L.cout : 0) + (double)L.taps * L.cin * L.cout);
+        e->prof.begin(e->stream, L.taps == 9 ? kc3 : kc1, flops, bytes);
+        hipError_t err = (L.taps == 9) ? launch_conv3x3(p, e->stream) : launch_conv1x1(p, e->stream);
+        e->prof.end(e->stream);
+        if (err != hipSuccess) {
+            set_error("conv launch failed: %s (Cin=%d Cout=%d H=%d W=%d)", hipGetErrorString(err), L.cin, L.cout, H, W);
+            return LM_ERR_DEVICE;
+        }
+        return LM_OK;
+    }
+};
+
+}  // namespace
+
+int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t* labels, float* logp) {
+    if (slot < 0 || slot >= 4 || !e->models[slot].loaded) {
+        set_error("model slot %d is empty", slot);
+        return LM_ERR_NOMODEL;
+    }
+    if (B <= 0 || H <= 0 || W <= 0 || (H & 15) || (W & 15)) {
+        set_error("lm_forward: need b>0 and h,w multiples of 16 (got %d,%d,%d)", B, H, W);
+        return LM_ERR_INVALID;
+    }
+    const Model& md = e->models[slot];
+    NNWorkspace& ws = e->nn;
+    const size_t px = (size_t)B * H * W;
+    LM_TRY(ws.t1.reserve(px * 64 * 4));
+    LM_TRY(ws.t2.reserve(px * 16 * 4));
+    LM_TRY(ws.t3.reserve(px * 64 * 4));
+    for (int i = 0; i < 4; ++i) {
+        LM_TRY(ws.cat[i].reserve((px >> (2 * i)) * (128u << i) * 4));
+        LM_TRY(ws.pool[i].reserve((px >> (2 * i + 2)) * (64u << i) * 4));
+    }
+    float *t1 = ws.t1.as<float>(), *t2 = ws.t2.as<float>(), *t3 = ws.t3.as<float>();
+    Fwd f{e, B, e->prof.kind_id("conv3x3_igemm_f32"), e->prof.kind_id("conv1x1_igemm_f32"), e->prof.kind_id("first_conv"),
+          e->prof.kind_id("upsample2x"), e->prof.kind_id("head_argmax")};
+
+    // ---- encoder (resunet.py:60-64)
+    {
+        FirstConvParams p{x, md.first.w, md.first.bias, md.first.bn_s, md.first.bn_t, t1, 64, 0, B, H, W};
+        e->prof.begin(e->stream, f.kfirst, 2.0 * px * 64 * 9, 4.0 * px * 65);
+        hipError_t err = launch_first_conv(p, e->stream);
+        e->prof.end(e->stream);
+        if (err != hipSuccess) {
+            set_error("first_conv launch failed: %s", hipGetErrorString(err));
+            return LM_ERR_DEVICE;
+        }
+    }
+    for (int i = 0; i < 5; ++i) {
+        const int h = H >> i, w = W >> i, c = 64 << i;
+        if (i > 0) LM_TRY(f.conv(md.down[i][0], ws.pool[i - 1].as<float>(), c / 2, 0, h, w, t1, c, 0));
+        if (i < 4)  // skip tensor goes straight into the second half of the level's concat buffer, pooled copy alongside
+            LM_TRY(f.conv(md.down[i][1], t1, c, 0, h, w, ws.cat[i].as<float>(), 2 * c, c, ws.pool[i].as<float>(), c, 0));
+        else
+            LM_TRY(f.conv(md.down[i][1], t1, c, 0, h, w, t3, c, 0));
+    }
+    // ---- decoder (resunet.py:66-67, :144-155).  conv1x1 and the bilinear upsample are both linear and the
+    // bilinear weights sum to one, so up.1(Upsample(x)) == Upsample(up.1(x)): run the 1x1 at LOW resolution.
+    for (int i = 0; i < 4; ++i) {
+        const int lvl = 3 - i;
+        const int h = H >> lvl, w = W >> lvl, c = 64 << lvl;
+        LM_TRY(f.conv(md.up1x1[i], t3, 2 * c, 0, h / 2, w / 2, t2, c, 0));
+        {
+            UpsampleParams p{t2, ws.cat[lvl].as<float>(), 2 * c, 0, B, h / 2, w / 2, c};
+            const double opx = (double)B * h * w;
+            e->prof.begin(e->stream, f.kup, 0, 4.0 * (opx * c + opx / 4 * c));
+            hipError_t err = launch_upsample2x(p, e->stream);
+            e->prof.end(e->stream);
+            if (err != hipSuccess) {
+                set_error("upsample launch failed: %s", hipGetErrorString(err));
+                return LM_ERR_DEVICE;
+            }
+        }
+        LM_TRY(f.conv(md.upc[i][0], ws.cat[lvl].as<float>(), 2 * c, 0, h, w, t1, c, 0));
+        LM_TRY(f.conv(md.upc[i][1], t1, c, 0, h, w, t3, c, 0));
+    }
+    // ---- head (resunet.py:69-70, mask.py:184-186)
+    {
+        HeadParams p{t3, md.head_w, md.head_b, labels, logp, B, H, W, md.n_classes};
+        e->prof.begin(e->stream, f.khead, 2.0 * px * 64 * md.n_classes, 4.0 * px * 64 + px);
+        hipError_t err = launch_head(p, e->stream);
+        e->prof.end(e->stream);
+        if (err != hipSuccess) {
+            set_error("head launch failed: %s", hipGetErrorString(err));
+            return LM_ERR_DEVICE;
+        }
+    }
+    return LM_OK;
+}
+
+}  // namespace lm

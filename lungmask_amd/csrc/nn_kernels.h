@@ -1,0 +1,63 @@
+// Kernel-side parameter blocks and launchers of the U-Net forward pass
+// (replaces torch's conv2d / relu / batch_norm / avg_pool2d / upsample / cat /
+// log_softmax / max as called from lungmask/resunet.py:58-70, mask.py:183-186).
+#pragma once
+#include "lm_platform.h"
+
+namespace lm {
+
+// Activations are NHWC fp32: element (b,y,x,c) of a tensor with `cstride`
+// channels per pixel lives at ((b*H + y)*W + x)*cstride + coff + c.  `coff`
+// lets a producer write straight into one half of a concat buffer
+// (resunet.py:147 torch.cat([up, bridge], 1) is therefore never materialised).
+struct ConvParams {
+    const float* in;
+    int in_cstride, in_coff;
+    const float* w;     // packed [taps][Cin][Cout]
+    const float* bias;  // [Cout]
+    const float* bn_s;  // [Cout] gamma/sqrt(var+eps)   (nullptr: no ReLU/BN epilogue)
+    const float* bn_t;  // [Cout] beta - mean*s
+    float* out;
+    int out_cstride, out_coff;
+    float* pool;  // optional avg_pool2d(2) of the output (nullptr: none)
+    int pool_cstride, pool_coff;
+    int B, H, W, Cin, Cout;
+};
+
+struct FirstConvParams {
+    const float* in;  // [B,H,W] single channel
+    const float* w;   // [9][64]
+    const float* bias;
+    const float* bn_s;
+    const float* bn_t;
+    float* out;
+    int out_cstride, out_coff;
+    int B, H, W;
+};
+
+struct UpsampleParams {
+    const float* in;  // [B,h,w,C] dense
+    float* out;       // [B,2h,2w,out_cstride] at out_coff
+    int out_cstride, out_coff;
+    int B, h, w, C;
+};
+
+struct HeadParams {
+    const float* in;  // [B,H,W,64] dense
+    const float* w;   // [C][64]
+    const float* bias;
+    uint8_t* labels;  // [B,H,W]            (nullptr: skip)
+    float* logp;      // [B,C,H,W] log-softmax (nullptr: skip)
+    int B, H, W, C;
+};
+
+// All launchers enqueue on `stream` and return hipGetLastError().
+hipError_t launch_conv3x3(const ConvParams& p, hipStream_t stream);
+hipError_t launch_conv1x1(const ConvParams& p, hipStream_t stream);
+hipError_t launch_first_conv(const FirstConvParams& p, hipStream_t stream);
+hipError_t launch_upsample2x(const UpsampleParams& p, hipStream_t stream);
+hipError_t launch_head(const HeadParams& p, hipStream_t stream);
+
+constexpr int kMaxClasses = 8;
+
+}  // namespace lm

@@ -1,0 +1,20 @@
+"""CPU suite: the HIP kernel SOURCES of the U-Net forward, executed through the
+tests/emu functional emulator at a tiny size, against the reference-generated
+golden (tolerance 1e-3 on log-probs per BASELINE.json north_star)."""
+import os
+
+import numpy as np
+
+from oracle import unet_oracle as uo
+
+TOL = 1e-3
+
+
+def test_forward_emulated_matches_reference_golden(emu_engine, golden_dir):
+    g = np.load(os.path.join(golden_dir, "unet_c3.npz"))
+    emu_engine.load_state_dict(0, uo.synthetic_state_dict(3))
+    x = g["rand32_x"][:1]
+    lab, logp = emu_engine.forward(0, x)
+    assert np.abs(logp - g["rand32_logp"][:1]).max() < TOL
+    bad = lab != g["rand32_lab"][:1]
+    assert not np.any(bad & (g["rand32_margin"][:1].astype(np.float32) > 2 * TOL))

@@ -1,0 +1,54 @@
+"""GPU parity of the network forward through the C ABI (lm_forward_dev)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_oracle as uo
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3  # BASELINE.json north_star: pre-argmax log-probs within 1e-3 (fp32)
+
+
+def check_labels(lab, ref_lab, margin, tol):
+    """Labels must be identical except on pixels whose reference top-2 margin is below 2*tol."""
+    bad = lab != ref_lab
+    n_bad = int(bad.sum())
+    assert not np.any(bad & (margin > 2 * tol)), f"{n_bad} mismatches, some away from near-ties"
+    return n_bad
+
+
+@pytest.mark.parametrize("C", [3, 6])
+def test_forward_matches_reference_goldens(gpu_engine, golden_dir, C):
+    g = np.load(os.path.join(golden_dir, f"unet_c{C}.npz"))
+    gpu_engine.load_state_dict(0, uo.synthetic_state_dict(C))
+    for case in ("rand32", "rand64", "phantom256"):
+        x = g[case + "_x"]
+        lab, logp = gpu_engine.forward(0, x)
+        ref = g[case + "_logp"]
+        got = logp if x.shape[-1] <= 64 else logp[:, :, ::4, ::4]
+        err = np.abs(got - ref).max()
+        assert err < TOL, (case, err)
+        check_labels(lab, g[case + "_lab"], g[case + "_margin"].astype(np.float32), TOL)
+
+
+def test_forward_batch20_vs_oracle(gpu_engine):
+    """BASELINE config batch (20 slices of 256x256) against the torch-fp32 CPU oracle."""
+    sd = uo.synthetic_state_dict(3)
+    gpu_engine.load_state_dict(0, sd)
+    rng = np.random.default_rng(5)
+    x = rng.random((20, 256, 256), dtype=np.float32)
+    lab, logp = gpu_engine.forward(0, x)
+    xs = torch.from_numpy(x[[0, 7, 19]][:, None])
+    with torch.inference_mode():
+        ref = uo.forward(sd, xs)
+    srt = torch.sort(ref, dim=1, descending=True)[0]
+    margin = (srt[:, 0] - srt[:, 1]).numpy()
+    ref = ref.numpy()
+    err = np.abs(logp[[0, 7, 19]] - ref).max()
+    assert err < TOL, err
+    check_labels(lab[[0, 7, 19]], ref.argmax(1).astype(np.uint8), margin, TOL)
+    # determinism: same input twice -> identical bytes
+    lab2, logp2 = gpu_engine.forward(0, x)
+    assert np.array_equal(lab, lab2) and np.array_equal(logp, logp2)

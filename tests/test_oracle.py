@@ -1,0 +1,90 @@
+"""The CPU oracle (oracle/) against the goldens generated from the REFERENCE
+implementation (oracle/make_golden.py) and against every known-answer value of
+the reference's tests/test_utils.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import prepost_oracle as po
+from oracle import unet_oracle as uo
+
+
+@pytest.fixture(scope="module")
+def gpp(golden_dir):
+    return np.load(os.path.join(golden_dir, "prepost.npz"))
+
+
+@pytest.mark.parametrize("C", [3, 6])
+def test_unet_oracle_matches_reference_class(golden_dir, C):
+    g = np.load(os.path.join(golden_dir, f"unet_c{C}.npz"))
+    sd = uo.synthetic_state_dict(C)
+    assert [k for k, _ in uo.state_dict_keys(C)] == list(sd.keys())
+    assert len(list(sd.values())[-1]) == C  # mask.py:56
+    for case in ("rand32", "rand64"):
+        x = torch.from_numpy(g[case + "_x"])
+        with torch.inference_mode():
+            y = uo.forward(sd, x).numpy()
+        assert np.abs(y - g[case + "_logp"]).max() < 1e-4
+        lab = uo.predict_labels(sd, x)
+        bad = lab != g[case + "_lab"]
+        assert not np.any(bad & (g[case + "_margin"].astype(np.float32) > 1e-3))
+
+
+def test_ref_known_answers_bbox3d():
+    m = np.zeros((10, 10, 10), dtype=np.uint8)
+    m[2:8, 3:7, 4:6] = 1
+    assert tuple(po.bbox_3D(m, margin=2)) == (0, 10, 1, 9, 2, 8)  # tests/test_utils.py:58-63
+
+
+def test_ref_known_answers_bodymask_crop_preprocess():
+    img = np.full((10, 10), dtype=np.int16, fill_value=-1000)
+    img[2:8, 3:7] = 1
+    img[9, 9] = 1
+    assert np.sum(po.simple_bodymask(img)) == 24  # :73-78
+    cropped, bb = po.crop_and_resize(img, width=20, height=20)  # :81-88
+    assert tuple(bb) == (2, 3, 8, 7) and cropped.shape == (20, 20) and np.sum(cropped) == 400
+    vol = np.tile(img[None], (2, 1, 1))
+    xs, bbs = po.preprocess(vol, resolution=[20, 20])  # :91-99
+    for sl, b in zip(xs, bbs):
+        assert tuple(b) == (2, 3, 8, 7) and sl.shape == (20, 20) and np.sum(sl) == 400
+
+
+def test_ref_known_answers_reshape_mask():
+    msk = np.full((10, 10), dtype=np.uint8, fill_value=1)
+    out = po.reshape_mask(msk, (2, 2, 22, 22), origsize=(30, 30))  # :102-107
+    assert out.shape == (30, 30) and np.sum(out) == 400
+
+
+def test_ref_known_answers_postprocessing():
+    li = np.zeros((1, 6, 6), dtype=np.uint8)
+    li[0] = np.asarray([[0, 0, 0, 0, 0, 0], [0, 1, 1, 2, 2, 0], [0, 2, 0, 3, 1, 0], [0, 4, 4, 4, 0, 0], [0, 4, 0, 4, 0, 0], [0, 4, 4, 4, 0, 0]])
+    gt = [[0, 0, 0, 0, 0, 0], [0, 1, 1, 2, 2, 0], [0, 1, 0, 3, 2, 0], [0, 4, 4, 4, 0, 0], [0, 4, 0, 4, 0, 0], [0, 4, 4, 4, 0, 0]]
+    t = np.tile(li, (2, 1, 1))
+    assert np.all(po.postprocessing(t, spare=[], skip_below=1)[0] == gt)  # :124-149
+    assert po.postprocessing(t, spare=[3], skip_below=1)[0][2, 3] == 2  # :151-154
+    assert po.postprocessing(t, spare=[3], skip_below=3)[0][2, 1] == 0  # :156-159
+
+
+def test_prepost_oracle_vs_reference_goldens(gpp):
+    g = gpp
+    for i in range(int(g["n_pre"])):
+        vol, res = g[f"pre{i}_vol"], [int(x) for x in g[f"pre{i}_res"]]
+        xs, boxes = po.preprocess(vol, res)
+        assert np.array_equal(xs, g[f"pre{i}_x"]) and xs.dtype == g[f"pre{i}_x"].dtype
+        assert np.array_equal(np.asarray(boxes, dtype=np.int32), g[f"pre{i}_box"])
+        bm = np.packbits(np.asarray([po.simple_bodymask(s) for s in np.clip(vol, -1024, 600)]).astype(bool), axis=-1)
+        assert np.array_equal(bm, g[f"pre{i}_bmask"])
+    for i in range(int(g["n_post"])):
+        out = po.postprocessing(g[f"post{i}_lab"].copy(), [int(x) for x in g[f"post{i}_spare"]], int(g[f"post{i}_skip"]))
+        assert np.array_equal(out, g[f"post{i}_out"]), i
+    for i in range(int(g["n_rs"])):
+        out = po.reshape_mask(g[f"rs{i}_mask"], [int(x) for x in g[f"rs{i}_box"]], tuple(int(x) for x in g[f"rs{i}_osz"]))
+        assert np.array_equal(out.astype(np.uint8), g[f"rs{i}_out"]), i
+    for i in range(int(g["n_klc"])):
+        m = g[f"klc{i}_mask"]
+        assert np.array_equal(np.packbits(po.keep_largest_connected_component(m)), g[f"klc{i}_out"])
+        assert np.array_equal(po.bbox_3D(m), g[f"klc{i}_bbox"])
+    for i in range(int(g["n_ac"])):
+        assert np.array_equal(po.area_closing_binary(g[f"ac{i}_img"]), g[f"ac{i}_out"])
