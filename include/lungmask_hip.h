@@ -78,6 +78,21 @@ int lm_model_classes(lm_engine* e, int slot);
 int lm_forward_dev(lm_engine* e, int slot, const float* x_dev, int b, int h, int w,
                    uint8_t* labels_dev, float* logp_dev);
 
+/* ---- pre-processing (utils.py:32-111 preprocess / simple_bodymask / crop_and_resize,
+ *      mask.py:166-168 clip + (x+1024)/1624) -------------------------------------- */
+/* vol_dev: [n][h][w] of `dtype` (LM_I16, LM_I32 or LM_I64).  Outputs (all dev):
+ *   bbox_dev   int32 [n][4]  body bounding box (r0,c0,r1,c1), utils.py:102-106
+ *   x_f32_dev  f32 [n][oh][ow] normalised network input        (or NULL)
+ *   x_i16_dev  i16 [n][oh][ow] == utils.preprocess()[0]        (or NULL)
+ *   bmask_dev  u8  [n][h][w]   == utils.simple_bodymask(slice) (or NULL; test seam) */
+int lm_preprocess_dev(lm_engine* e, const void* vol_dev, int dtype, int n, int h, int w, int oh, int ow,
+                      int32_t* bbox_dev, float* x_f32_dev, int16_t* x_i16_dev, uint8_t* bmask_dev);
+
+/* ---- mask un-crop (utils.py:114-129 reshape_mask, mask.py:196-202) --------------- */
+/* mask_dev u8 [n][mh][mw], bbox_dev int32 [n][4] -> out_dev u8 [n][h][w]. */
+int lm_reshape_mask_dev(lm_engine* e, const uint8_t* mask_dev, const int32_t* bbox_dev, int n, int mh, int mw,
+                        int h, int w, uint8_t* out_dev);
+
 /* Per-kernel timing of the network launches since the last reset (HIP events on
  * the engine stream; enabled with lm_profile_enable(e, 1)).  Returns the number
  * of distinct kernel kinds; fills up to `cap` entries. */

@@ -63,6 +63,8 @@ class Library:
         L.lm_model_load.argtypes = [C.c_void_p, C.c_int, C.POINTER(_Tensor), C.c_int]
         L.lm_model_classes.argtypes = [C.c_void_p, C.c_int]
         L.lm_forward_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.lm_preprocess_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_int] * 5 + [C.c_void_p] * 4
+        L.lm_reshape_mask_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
         L.lm_profile_enable.argtypes = [C.c_void_p, C.c_int]
         L.lm_profile_reset.argtypes = [C.c_void_p]
         L.lm_profile_read.argtypes = [C.c_void_p, C.POINTER(KernelStat), C.c_int]
@@ -202,6 +204,55 @@ class Engine:
         for d in (xd, ld, pd):
             if d is not None:
                 d.free()
+        return out
+
+    # -- pre-processing
+    def preprocess_dev(self, vol: DeviceArray, bbox: DeviceArray, x_f32: Optional[DeviceArray] = None,
+                       x_i16: Optional[DeviceArray] = None, bmask: Optional[DeviceArray] = None, resolution=(256, 256)):
+        n, h, w = vol.shape
+        if vol.dtype not in LM_DTYPES:
+            raise LMError(f"unsupported volume dtype {vol.dtype}")
+        self.L.check(
+            self.L.lib.lm_preprocess_dev(self.h, vol.ptr, LM_DTYPES[vol.dtype], n, h, w, int(resolution[0]), int(resolution[1]), bbox.ptr,
+                                         x_f32.ptr if x_f32 else None, x_i16.ptr if x_i16 else None, bmask.ptr if bmask else None),
+            "lm_preprocess_dev",
+        )
+
+    def preprocess(self, vol: np.ndarray, resolution=(256, 256), want_bmask: bool = False):
+        """== utils.preprocess + normalisation: returns (x_i16 [n,oh,ow], x_f32, bbox int32 [n,4], bmask|None)."""
+        vol = np.ascontiguousarray(vol)
+        n, h, w = vol.shape
+        vd = self.to_device(vol)
+        bb = self.empty((n, 4), np.int32)
+        xf = self.empty((n, resolution[0], resolution[1]), np.float32)
+        xi = self.empty((n, resolution[0], resolution[1]), np.int16)
+        bm = self.empty((n, h, w), np.uint8) if want_bmask else None
+        self.preprocess_dev(vd, bb, xf, xi, bm, resolution)
+        self.sync()
+        out = xi.download(), xf.download(), bb.download(), (bm.download() if bm else None)
+        for d in (vd, bb, xf, xi, bm):
+            if d is not None:
+                d.free()
+        return out
+
+    def reshape_mask_dev(self, mask: DeviceArray, bbox: DeviceArray, out: DeviceArray):
+        n, mh, mw = mask.shape
+        _, h, w = out.shape
+        self.L.check(self.L.lib.lm_reshape_mask_dev(self.h, mask.ptr, bbox.ptr, n, mh, mw, h, w, out.ptr), "lm_reshape_mask_dev")
+
+    def reshape_mask(self, mask: np.ndarray, bbox: np.ndarray, origsize) -> np.ndarray:
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        if mask.ndim == 2:
+            mask, bbox = mask[None], np.asarray(bbox)[None]
+        n = mask.shape[0]
+        md = self.to_device(mask)
+        bd = self.to_device(np.ascontiguousarray(bbox, dtype=np.int32).reshape(n, 4))
+        od = self.empty((n, int(origsize[0]), int(origsize[1])), np.uint8)
+        self.reshape_mask_dev(md, bd, od)
+        self.sync()
+        out = od.download()
+        for d in (md, bd, od):
+            d.free()
         return out
 
     # -- profiling

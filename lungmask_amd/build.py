@@ -52,7 +52,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         obj = os.path.join(objdir, os.path.basename(src).replace(".hip", ".o"))
         objs.append(obj)
         if force or _newer(obj, [src] + hdrs):
-            jobs.append([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj])
+            jobs.append([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-c", src, "-o", obj])
     _run_all(jobs, verbose)
     if jobs or not os.path.exists(LIB):
         _run_all([[hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs], verbose)
@@ -73,7 +73,7 @@ def build_emu(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(outdir, os.path.basename(s).rsplit(".", 1)[0] + ".o")
         objs.append(obj)
         if force or _newer(obj, [s] + hdrs):
-            cmds.append(["g++", "-x", "c++", "-std=c++17", "-O2", "-fopenmp", "-fPIC", "-DLM_EMU_BUILD", "-I", emu, "-I", CSRC, "-c", s, "-o", obj])
+            cmds.append(["g++", "-x", "c++", "-std=c++17", "-O2", "-ffp-contract=off", "-fopenmp", "-fPIC", "-DLM_EMU_BUILD", "-I", emu, "-I", CSRC, "-c", s, "-o", obj])
     _run_all(cmds, verbose)
     if cmds or not os.path.exists(lib):
         _run_all([["g++", "-shared", "-fopenmp", "-o", lib] + objs], verbose)

@@ -1,5 +1,6 @@
 // extern "C" surface of liblungmask_hip.so (include/lungmask_hip.h).
 #include "engine.h"
+#include "pre_kernels.h"
 
 using namespace lm;
 
@@ -98,6 +99,56 @@ int lm_model_classes(lm_engine* e, int slot) {
 int lm_forward_dev(lm_engine* e, int slot, const float* x_dev, int b, int h, int w, uint8_t* labels_dev, float* logp_dev) {
     if (!e || !x_dev) return LM_ERR_INVALID;
     return forward(e, slot, x_dev, b, h, w, labels_dev, logp_dev);
+}
+
+int lm_preprocess_dev(lm_engine* e, const void* vol_dev, int dtype, int n, int h, int w, int oh, int ow, int32_t* bbox_dev,
+                      float* x_f32_dev, int16_t* x_i16_dev, uint8_t* bmask_dev) {
+    if (!e || !vol_dev || !bbox_dev || n < 0 || h <= 0 || w <= 0 || oh <= 0 || ow <= 0) {
+        set_error("lm_preprocess_dev: bad arguments");
+        return LM_ERR_INVALID;
+    }
+    if (dtype != LM_I16 && dtype != LM_I32 && dtype != LM_I64) {
+        set_error("lm_preprocess_dev: unsupported dtype code %d (integer HU volumes only)", dtype);
+        return LM_ERR_INVALID;
+    }
+    BodyMaskParams bp{vol_dev, dtype, n, h, w, bbox_dev, bmask_dev};
+    const double vox = (double)n * h * w;
+    const int esz = dtype == LM_I16 ? 2 : (dtype == LM_I32 ? 4 : 8);
+    e->prof.begin(e->stream, e->prof.kind_id("bodymask_bbox"), 0, (double)n * 128 * 128 * esz);
+    hipError_t err = launch_bodymask_bbox(bp, e->stream);
+    e->prof.end(e->stream);
+    if (err != hipSuccess) {
+        set_error("bodymask launch failed: %s", hipGetErrorString(err));
+        return LM_ERR_DEVICE;
+    }
+    if (x_f32_dev || x_i16_dev) {
+        ResampleParams rp{vol_dev, dtype, n, h, w, bbox_dev, oh, ow, x_i16_dev, x_f32_dev};
+        e->prof.begin(e->stream, e->prof.kind_id("resample_norm"), 0, vox * esz + (double)n * oh * ow * 4);
+        err = launch_resample_norm(rp, e->stream);
+        e->prof.end(e->stream);
+        if (err != hipSuccess) {
+            set_error("resample launch failed: %s", hipGetErrorString(err));
+            return LM_ERR_DEVICE;
+        }
+    }
+    return LM_OK;
+}
+
+int lm_reshape_mask_dev(lm_engine* e, const uint8_t* mask_dev, const int32_t* bbox_dev, int n, int mh, int mw, int h, int w,
+                        uint8_t* out_dev) {
+    if (!e || !mask_dev || !bbox_dev || !out_dev || n < 0 || mh <= 0 || mw <= 0 || h <= 0 || w <= 0) {
+        set_error("lm_reshape_mask_dev: bad arguments");
+        return LM_ERR_INVALID;
+    }
+    ReshapeParams p{mask_dev, bbox_dev, out_dev, n, mh, mw, h, w};
+    e->prof.begin(e->stream, e->prof.kind_id("reshape_mask"), 0, (double)n * ((double)mh * mw + (double)h * w));
+    hipError_t err = launch_reshape_mask(p, e->stream);
+    e->prof.end(e->stream);
+    if (err != hipSuccess) {
+        set_error("reshape_mask launch failed: %s", hipGetErrorString(err));
+        return LM_ERR_DEVICE;
+    }
+    return LM_OK;
 }
 
 int lm_profile_enable(lm_engine* e, int on) {

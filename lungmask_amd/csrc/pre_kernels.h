@@ -1,0 +1,37 @@
+// Parameter blocks / launchers of the pre-processing kernels (pre_kernels.hip).
+#pragma once
+#include "../../include/lungmask_hip.h"
+#include "lm_platform.h"
+
+namespace lm {
+
+struct BodyMaskParams {
+    const void* vol;  // [N][H][W] of `dtype`
+    int dtype;        // LM_I16 / LM_I32 / LM_I64
+    int N, H, W;
+    int* bbox;       // [N][4] = (r0, c0, r1, c1) half-open, utils.py:102-106
+    uint8_t* bmask;  // optional [N][H][W] full-resolution body mask (test seam), else nullptr
+};
+
+struct ResampleParams {
+    const void* vol;
+    int dtype;
+    int N, H, W;
+    const int* bbox;
+    int OH, OW;        // 256 x 256 (mask.py:166)
+    int16_t* out_i16;  // optional [N][OH][OW]: utils.preprocess output
+    float* out_f32;    // optional [N][OH][OW]: normalised network input (mask.py:167-168,178-181)
+};
+
+struct ReshapeParams {
+    const uint8_t* mask;  // [N][MH][MW]
+    const int* bbox;      // [N][4]
+    uint8_t* out;         // [N][H][W]
+    int N, MH, MW, H, W;
+};
+
+hipError_t launch_bodymask_bbox(const BodyMaskParams& p, hipStream_t stream);
+hipError_t launch_resample_norm(const ResampleParams& p, hipStream_t stream);
+hipError_t launch_reshape_mask(const ReshapeParams& p, hipStream_t stream);
+
+}  // namespace lm
