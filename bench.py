@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""bench.py -- CT slices/s of the lungmask hot path (`LMInferer.apply`) on MI355X.
+
+One "step" = one pass of the whole hot path (body-mask crop + 256x256 resample ->
+U-Net forward in batches of 20 -> argmax -> 3-D connected-component clean-up ->
+un-crop) over a synthetic 512x512 int16 HU volume that is already resident in
+HBM; the uint8 label volume is left in HBM.  Workload = BASELINE.json configs[1]
+(R231, 512x512x300, batchsize=20) per GPU; with N GPUs the volume has 300*N
+slices, slice-sharded, with the RCCL all-gathers of lungmask_amd/pipeline.py
+(weak scaling).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
+FLOP_PER_SLICE = 96.200556544e9  # R231, SURVEY.md Appendix A (algorithmic, 256x256)
+
+
+def cpu_baseline(n_sample, sd):
+    """The reference algorithm restated on the CPU (oracle/, kind='port'), timed on this host's cores on a
+    bounded sample: n_sample central slices of the same phantom, batch 1 (what the reference's --cpu forces)."""
+    import torch
+
+    from oracle import prepost_oracle as po
+    from oracle import unet_oracle as uo
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    z0 = 150 - n_sample // 2
+    vol = po.phantom(300, 512, 512, z0=z0, z1=z0 + n_sample)
+
+    def predict(xb):
+        return uo.predict_labels(sd, torch.from_numpy(np.ascontiguousarray(xb)))
+
+    predict(np.zeros((1, 1, 256, 256), np.float32))  # warm-up
+    t = time.perf_counter()
+    po.inference(vol, predict, batch_size=1)
+    dt = time.perf_counter() - t
+    return {
+        "value": n_sample / dt,
+        "unit": "slices/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{n_sample} central slices (z={z0}..{z0 + n_sample - 1}) of the 512x512x300 phantom, batch 1, torch-CPU fp32 forward + scipy pre/post, {dt:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--slices", type=int, default=300, help="slices per GPU")
+    ap.add_argument("--batch", type=int, default=20)
+    ap.add_argument("--cpu-sample", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+
+    from lungmask_amd import _native as nat
+    from oracle import prepost_oracle as po
+    from oracle import unet_oracle as uo
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    eng = nat.Engine(local_rank)  # raises if liblungmask_hip.so or the GPU is missing: no fallback
+    weights = "synthetic (oracle.unet_oracle.synthetic_state_dict, seed 231)"
+    sd = None
+    wd = os.environ.get("LUNGMASK_WEIGHTS_DIR")
+    if wd and os.path.exists(os.path.join(wd, "unet_r231-d5d2fc3d.pth")):
+        sd = torch.load(os.path.join(wd, "unet_r231-d5d2fc3d.pth"), map_location="cpu")
+        weights = "pretrained unet_r231-d5d2fc3d.pth"
+    if sd is None:
+        sd = uo.synthetic_state_dict(3)
+    eng.load_state_dict(0, sd)
+
+    n_local, n_total = args.slices, args.slices * world
+    vol = po.phantom(n_total, 512, 512, z0=rank * n_local, z1=(rank + 1) * n_local)
+
+    def sync_all():
+        eng.sync()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    if world == 1:
+        vd = eng.to_device(vol)
+        od = eng.empty(vol.shape, np.uint8)
+
+        def step():
+            eng.apply_dev(0, vd, od, batch_size=args.batch)
+    else:
+        from lungmask_amd.pipeline import ShardedPipeline
+
+        dev = torch.device("cuda", local_rank)
+        vt = torch.from_numpy(vol).to(dev)
+        pipe = ShardedPipeline(eng, slot=0, batch_size=args.batch, dist=dist, device=dev)
+
+        def step():
+            pipe.apply_shard(vt, n_total)
+
+    for _ in range(args.warmup):
+        step()
+    eng.profile(True)
+    eng.profile_reset()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    stats = eng.profile_read()
+    eng.profile(False)
+    post_info = eng.postprocess_info()
+
+    if rank == 0:
+        value = n_total * args.steps / dt
+        conv = next((s for s in stats if s["name"] == "conv3x3_igemm_f32"), None)
+        roof = None
+        if conv and conv["total_ms"] > 0:
+            ach = conv["flops"] / (conv["total_ms"] * 1e-3) / 1e12
+            roof = {
+                "bound": "mfma",
+                "kernel": "conv3x3_igemm_f32 (v_mfma_f32_32x32x2_f32, exact fp32)",
+                "achieved": round(ach, 2),
+                "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                "traffic": None,
+                "launches": conv["launches"],
+                "avg_launch_ms": round(conv["total_ms"] / conv["launches"], 4),
+                "algorithmic_flop_per_launch": conv["flops"] / conv["launches"],
+                "note": "aggregate over the 17 conv3x3 launches of every batch (rank 0), HIP events on the engine stream",
+            }
+        out = {
+            "metric": "CT slices/sec (whole node), R231 512x512 volume",
+            "value": round(value, 2),
+            "unit": "slices/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"R231 U-Net, 512x512x{n_local} int16 HU phantom per GPU ({n_total} slices total), batchsize={args.batch}, "
+                            "LMInferer.apply device-resident (pre + forward + argmax + 3-D post + un-crop)",
+                "weights": weights,
+                "parallelism": "single GPU" if world == 1 else f"slice-sharded x{world}, 2 RCCL all-gathers (labels, output)",
+            },
+            "end_to_end_tflops": round(value * FLOP_PER_SLICE / 1e12, 2),
+            "roofline": roof,
+            "stages_ms_per_step": {s["name"]: round(s["total_ms"] / args.steps, 3) for s in stats},
+            "postprocessing": post_info,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, sd)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -93,6 +93,29 @@ int lm_preprocess_dev(lm_engine* e, const void* vol_dev, int dtype, int n, int h
 int lm_reshape_mask_dev(lm_engine* e, const uint8_t* mask_dev, const int32_t* bbox_dev, int n, int mh, int mw,
                         int h, int w, uint8_t* out_dev);
 
+/* ---- volume post-processing (utils.py:272-358 postprocessing incl. :361-404 bbox_3D /
+ *      keep_largest_connected_component and the hole filler of :344-352) -------------- */
+/* lab_dev u8 [n][h][w], processed IN PLACE.  spare: label values that are merged into
+ * neighbours and dropped (fusion), may be NULL; skip_below: utils.py default 3. */
+int lm_postprocess_dev(lm_engine* e, uint8_t* lab_dev, int n, int h, int w, const int* spare, int n_spare,
+                       int skip_below);
+/* What the last lm_postprocess_dev saw: info[0]=regions, [1]=boundary voxels shipped to the
+ * host, [2]=regions processed by the merge loop, [3]=regions merged, [4]=host replay in us. */
+int lm_postprocess_info(lm_engine* e, int64_t info[5]);
+
+/* ---- label fusion (mask.py:228-230): res_l <- fuse(res_l, res_r); returns the spare label -- */
+int lm_fuse_dev(lm_engine* e, uint8_t* res_l_dev, const uint8_t* res_r_dev, size_t nvox, int* spare_out);
+
+/* ---- the whole hot path: LMInferer.apply on a numpy volume (mask.py:212-232) ---------- */
+/* slot: model; fill_slot: fill model for the fused LTRCLobes_R231 mode or -1.
+ * vol: [n][h][w] of `dtype` (LM_I16/LM_I32/LM_I64); out: u8 [n][h][w].
+ * batch_size, volume_postprocessing: the LMInferer constructor arguments (mask.py:72-82).
+ * _dev: both buffers already in HBM, nothing leaves the device.  _host: does the H2D / D2H. */
+int lm_apply_dev(lm_engine* e, int slot, int fill_slot, const void* vol_dev, int dtype, int n, int h, int w,
+                 int batch_size, int volume_postprocessing, uint8_t* out_dev);
+int lm_apply_host(lm_engine* e, int slot, int fill_slot, const void* vol_host, int dtype, int n, int h, int w,
+                  int batch_size, int volume_postprocessing, uint8_t* out_host);
+
 /* Per-kernel timing of the network launches since the last reset (HIP events on
  * the engine stream; enabled with lm_profile_enable(e, 1)).  Returns the number
  * of distinct kernel kinds; fills up to `cap` entries. */

@@ -65,6 +65,11 @@ class Library:
         L.lm_forward_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.lm_preprocess_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_int] * 5 + [C.c_void_p] * 4
         L.lm_reshape_mask_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
+        L.lm_postprocess_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]
+        L.lm_postprocess_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        L.lm_fuse_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]
+        L.lm_apply_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
+        L.lm_apply_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
         L.lm_profile_enable.argtypes = [C.c_void_p, C.c_int]
         L.lm_profile_reset.argtypes = [C.c_void_p]
         L.lm_profile_read.argtypes = [C.c_void_p, C.POINTER(KernelStat), C.c_int]
@@ -253,6 +258,60 @@ class Engine:
         out = od.download()
         for d in (md, bd, od):
             d.free()
+        return out
+
+    # -- post-processing
+    def postprocess_dev(self, lab: DeviceArray, spare: Sequence[int] = (), skip_below: int = 3):
+        n, h, w = lab.shape
+        sp = (C.c_int * max(len(spare), 1))(*[int(s) for s in spare])
+        self.L.check(self.L.lib.lm_postprocess_dev(self.h, lab.ptr, n, h, w, sp, len(spare), int(skip_below)), "lm_postprocess_dev")
+
+    def postprocess(self, lab: np.ndarray, spare: Sequence[int] = (), skip_below: int = 3) -> np.ndarray:
+        """== utils.postprocessing(label_image, spare, skip_below=...)."""
+        ld = self.to_device(np.ascontiguousarray(lab, dtype=np.uint8))
+        self.postprocess_dev(ld, spare, skip_below)
+        self.sync()
+        out = ld.download()
+        ld.free()
+        return out
+
+    def postprocess_info(self) -> dict:
+        buf = (C.c_int64 * 5)()
+        self.L.check(self.L.lib.lm_postprocess_info(self.h, buf))
+        return dict(regions=buf[0], boundary_records=buf[1], processed=buf[2], merged=buf[3], host_replay_ms=buf[4] / 1000.0)
+
+    def fuse(self, res_l: np.ndarray, res_r: np.ndarray):
+        """mask.py:228-230 -> (fused volume incl. spare label, spare value)."""
+        ld = self.to_device(np.ascontiguousarray(res_l, dtype=np.uint8))
+        rd = self.to_device(np.ascontiguousarray(res_r, dtype=np.uint8))
+        sp = C.c_int()
+        self.L.check(self.L.lib.lm_fuse_dev(self.h, ld.ptr, rd.ptr, ld.nbytes, C.byref(sp)), "lm_fuse_dev")
+        self.sync()
+        out = ld.download()
+        ld.free()
+        rd.free()
+        return out, sp.value
+
+    # -- the whole hot path
+    def apply_dev(self, slot: int, vol: DeviceArray, out: DeviceArray, fill_slot: int = -1, batch_size: int = 20, volume_postprocessing: bool = True):
+        n, h, w = vol.shape
+        if vol.dtype not in LM_DTYPES:
+            raise LMError(f"unsupported volume dtype {vol.dtype}")
+        self.L.check(
+            self.L.lib.lm_apply_dev(self.h, slot, fill_slot, vol.ptr, LM_DTYPES[vol.dtype], n, h, w, int(batch_size), int(bool(volume_postprocessing)), out.ptr),
+            "lm_apply_dev",
+        )
+
+    def apply(self, slot: int, vol: np.ndarray, fill_slot: int = -1, batch_size: int = 20, volume_postprocessing: bool = True) -> np.ndarray:
+        vol = np.ascontiguousarray(vol)
+        if vol.dtype not in LM_DTYPES:
+            raise LMError(f"unsupported volume dtype {vol.dtype}")
+        n, h, w = vol.shape
+        out = np.empty((n, h, w), dtype=np.uint8)
+        self.L.check(
+            self.L.lib.lm_apply_host(self.h, slot, fill_slot, vol.ctypes.data, LM_DTYPES[vol.dtype], n, h, w, int(batch_size), int(bool(volume_postprocessing)), out.ctypes.data),
+            "lm_apply_host",
+        )
         return out
 
     # -- profiling

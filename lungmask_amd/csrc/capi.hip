@@ -1,5 +1,6 @@
 // extern "C" surface of liblungmask_hip.so (include/lungmask_hip.h).
 #include "engine.h"
+#include "post_kernels.h"
 #include "pre_kernels.h"
 
 using namespace lm;
@@ -44,13 +45,9 @@ void lm_engine_destroy(lm_engine* e) {
     (void)hipStreamSynchronize(e->stream);
     e->prof.release();
     for (auto& m : e->models) m.release();
-    e->nn.t1.release();
-    e->nn.t2.release();
-    e->nn.t3.release();
-    for (int i = 0; i < 4; ++i) {
-        e->nn.cat[i].release();
-        e->nn.pool[i].release();
-    }
+    e->nn.release();
+    e->post.release();
+    e->app.release();
     (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -148,6 +145,76 @@ int lm_reshape_mask_dev(lm_engine* e, const uint8_t* mask_dev, const int32_t* bb
         set_error("reshape_mask launch failed: %s", hipGetErrorString(err));
         return LM_ERR_DEVICE;
     }
+    return LM_OK;
+}
+
+int lm_postprocess_dev(lm_engine* e, uint8_t* lab_dev, int n, int h, int w, const int* spare, int n_spare, int skip_below) {
+    if (!e || !lab_dev || n < 0 || h <= 0 || w <= 0 || n_spare < 0) {
+        set_error("lm_postprocess_dev: bad arguments");
+        return LM_ERR_INVALID;
+    }
+    return postprocess(e, lab_dev, n, h, w, spare, n_spare, skip_below);
+}
+
+int lm_postprocess_info(lm_engine* e, int64_t info[5]) {
+    if (!e || !info) return LM_ERR_INVALID;
+    info[0] = e->post_info.regions;
+    info[1] = e->post_info.boundary_records;
+    info[2] = e->post_info.processed;
+    info[3] = e->post_info.merged;
+    info[4] = (int64_t)(e->post_info.host_replay_ms * 1000.0);
+    return LM_OK;
+}
+
+int lm_fuse_dev(lm_engine* e, uint8_t* res_l_dev, const uint8_t* res_r_dev, size_t nvox, int* spare_out) {
+    if (!e || !res_l_dev || !res_r_dev) return LM_ERR_INVALID;
+    LM_TRY(e->post.scalars.reserve(4096));
+    unsigned* mx_dev = e->post.scalars.as<unsigned>() + 2;
+    hipError_t err = volume_max(res_l_dev, mx_dev, nvox, e->stream);
+    if (err != hipSuccess) {
+        set_error("volume_max failed: %s", hipGetErrorString(err));
+        return LM_ERR_DEVICE;
+    }
+    unsigned mx = 0;
+    LM_HIP(hipMemcpyAsync(&mx, mx_dev, sizeof mx, hipMemcpyDeviceToHost, e->stream));
+    LM_HIP(hipStreamSynchronize(e->stream));
+    const int spare = (int)((mx + 1) & 0xff);
+    err = fuse_labels(res_l_dev, res_r_dev, (uint8_t)spare, nvox, e->stream);
+    if (err != hipSuccess) {
+        set_error("fuse_labels failed: %s", hipGetErrorString(err));
+        return LM_ERR_DEVICE;
+    }
+    if (spare_out) *spare_out = spare;
+    return LM_OK;
+}
+
+int lm_apply_dev(lm_engine* e, int slot, int fill_slot, const void* vol_dev, int dtype, int n, int h, int w, int batch_size,
+                 int volume_postprocessing, uint8_t* out_dev) {
+    if (!e || !vol_dev || !out_dev || n < 0 || h <= 0 || w <= 0) {
+        set_error("lm_apply_dev: bad arguments");
+        return LM_ERR_INVALID;
+    }
+    return apply_volume(e, slot, fill_slot, vol_dev, dtype, n, h, w, batch_size, volume_postprocessing, out_dev);
+}
+
+int lm_apply_host(lm_engine* e, int slot, int fill_slot, const void* vol_host, int dtype, int n, int h, int w, int batch_size,
+                  int volume_postprocessing, uint8_t* out_host) {
+    if (!e || !vol_host || !out_host || n < 0 || h <= 0 || w <= 0) {
+        set_error("lm_apply_host: bad arguments");
+        return LM_ERR_INVALID;
+    }
+    const int esz = dtype == LM_I16 ? 2 : (dtype == LM_I32 ? 4 : (dtype == LM_I64 ? 8 : 0));
+    if (!esz) {
+        set_error("lm_apply_host: unsupported dtype code %d (integer HU volumes only)", dtype);
+        return LM_ERR_INVALID;
+    }
+    const size_t nvox = (size_t)n * h * w;
+    LM_TRY(e->app.vol.reserve(nvox * esz));
+    LM_TRY(e->app.out.reserve(nvox));
+    LM_HIP(hipMemcpyAsync(e->app.vol.p, vol_host, nvox * esz, hipMemcpyHostToDevice, e->stream));
+    LM_TRY(apply_volume(e, slot, fill_slot, e->app.vol.p, dtype, n, h, w, batch_size, volume_postprocessing, e->app.out.as<uint8_t>()));
+    LM_HIP(hipMemcpyAsync(out_host, e->app.out.p, nvox, hipMemcpyDeviceToHost, e->stream));
+    LM_HIP(hipStreamSynchronize(e->stream));
     return LM_OK;
 }
 

@@ -79,6 +79,29 @@ struct Profiler {
 
 struct NNWorkspace {
     DevBuf t1, t2, t3, cat[4], pool[4];
+    void release() {
+        t1.release(); t2.release(); t3.release();
+        for (int i = 0; i < 4; ++i) { cat[i].release(); pool[i].release(); }
+    }
+};
+
+struct PostWorkspace {
+    DevBuf parent, ids, rank, bgparent, blockcnt, area, labval, recs, lut, mapped, bg, out, scalars;
+    void release() {
+        parent.release(); ids.release(); rank.release(); bgparent.release(); blockcnt.release(); area.release(); labval.release();
+        recs.release(); lut.release(); mapped.release(); bg.release(); out.release(); scalars.release();
+    }
+};
+
+struct ApplyWorkspace {
+    DevBuf vol, xf, bbox, labels, res_r, out;
+    void release() { vol.release(); xf.release(); bbox.release(); labels.release(); res_r.release(); out.release(); }
+};
+
+// What the last lm_postprocess_dev call saw (reported by bench.py next to the timing: it is data dependent).
+struct PostInfo {
+    long long regions = 0, boundary_records = 0, merged = 0, processed = 0;
+    double host_replay_ms = 0;
 };
 
 }  // namespace lm
@@ -88,10 +111,16 @@ struct lm_engine {
     hipStream_t stream = nullptr;
     lm::Model models[4];
     lm::NNWorkspace nn;
+    lm::PostWorkspace post;
+    lm::ApplyWorkspace app;
+    lm::PostInfo post_info;
     lm::Profiler prof;
 };
 
 namespace lm {
 int model_load(lm_engine* e, int slot, const lm_tensor* tensors, int n);
 int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t* labels, float* logp);
+int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spare, int n_spare, int skip_below);
+int apply_volume(lm_engine* e, int slot, int fill_slot, const void* vol_dev, int dtype, int n, int h, int w, int batch_size,
+                 int volume_postprocessing, uint8_t* out_dev);
 }  // namespace lm

@@ -1,0 +1,327 @@
+// Host orchestration of utils.postprocessing (utils.py:272-358) and of the whole
+// LMInferer.apply pipeline (mask.py:141-232) over device-resident volumes.
+//
+// Voxel-level work (3-D labelling, region statistics, boundary extraction, LUT
+// mapping, largest component, hole filling) runs in post_kernels.hip.  The
+// reference's region-merge loop (utils.py:310-339) is sequential and
+// order-dependent by construction; it is replayed here on the region graph:
+// every voxel that touches another region is shipped once as a BoundaryRec, and
+// the shell histogram "np.unique(sub[dilated], return_counts=True)" of a
+// (possibly already merged) region is recomputed from those records with a
+// per-record stamp, so a voxel adjacent to several members of the region counts
+// once -- exactly the 6-connected binary_dilation of utils.py:317.
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <numeric>
+
+#include "engine.h"
+#include "post_kernels.h"
+#include "pre_kernels.h"
+
+namespace lm {
+
+namespace {
+
+#define LM_K(expr)                                                              \
+    do {                                                                        \
+        hipError_t _e = (expr);                                                 \
+        if (_e != hipSuccess) {                                                 \
+            set_error("%s failed: %s", #expr, hipGetErrorString(_e));           \
+            return LM_ERR_DEVICE;                                               \
+        }                                                                       \
+    } while (0)
+
+struct ProfScope {
+    lm_engine* e;
+    ProfScope(lm_engine* e_, const char* name, double bytes) : e(e_) { e->prof.begin(e->stream, e->prof.kind_id(name), 0, bytes); }
+    ~ProfScope() { e->prof.end(e->stream); }
+};
+
+// utils.py:303-342 on the region graph.  Returns lut[atom] = final label value (0 = removed).
+void replay_merge(int R, const std::vector<int>& area, const std::vector<uint8_t>& lv, const std::vector<BoundaryRec>& recs,
+                  const std::vector<int>& spare, int skip_below, std::vector<uint8_t>& lut, PostInfo& info) {
+    std::vector<int> order(R);
+    std::iota(order.begin(), order.end(), 1);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return area[a] < area[b]; });  // :299
+    unsigned maxsub[256];
+    memset(maxsub, 0, sizeof maxsub);
+    std::vector<uint8_t> lobemap(R + 1, 0);
+    std::vector<long long> cache_area(area.begin(), area.end());
+    for (int r : order) {  // :303-308
+        const int mi = lv[r];
+        if (cache_area[r] > (long long)maxsub[mi]) {
+            maxsub[mi] = (unsigned)cache_area[r];
+            lobemap[r] = (uint8_t)mi;
+        }
+    }
+    bool spare_label[256];
+    memset(spare_label, 0, sizeof spare_label);
+    for (int s : spare)
+        if (s >= 0 && s < 256) spare_label[s] = true;
+    auto id_in_spare = [&](int id) {  // utils.py:323 compares a REGION ID with the spare LABEL values
+        for (int s : spare)
+            if (s == id) return true;
+        return false;
+    };
+    // adjacency: atom -> records in which it appears as a neighbour
+    std::vector<unsigned> adj_off(R + 2, 0);
+    for (const BoundaryRec& rc : recs)
+        for (int k = 0; k < 6 && rc.nb[k]; ++k) adj_off[rc.nb[k] + 1]++;
+    for (int i = 1; i <= R + 1; ++i) adj_off[i] += adj_off[i - 1];
+    std::vector<unsigned> adj(adj_off[R + 1]);
+    {
+        std::vector<unsigned> fill(adj_off.begin(), adj_off.end() - 1);
+        for (size_t j = 0; j < recs.size(); ++j)
+            for (int k = 0; k < 6 && recs[j].nb[k]; ++k) adj[fill[recs[j].nb[k]]++] = (unsigned)j;
+    }
+    // current id of every atom: union-find + member lists
+    std::vector<int> uf(R + 1), setid(R + 1), head(R + 1), tail(R + 1), next(R + 1, 0), rep(R + 1);
+    for (int i = 0; i <= R; ++i) uf[i] = setid[i] = head[i] = tail[i] = rep[i] = i;
+    auto find = [&](int a) {
+        while (uf[a] != a) {
+            uf[a] = uf[uf[a]];
+            a = uf[a];
+        }
+        return a;
+    };
+    std::vector<int> stamp(recs.size(), 0), counts(R + 1, 0), touched;
+    for (int r : order) {  // :310-339
+        const int mi = lv[r];
+        if (!((cache_area[r] < (long long)maxsub[mi] || spare_label[mi]) && cache_area[r] >= skip_below)) continue;
+        info.processed++;
+        touched.clear();
+        for (int a = head[r]; a; a = next[a]) {
+            for (unsigned q = adj_off[a]; q < adj_off[a + 1]; ++q) {
+                const unsigned j = adj[q];
+                if (stamp[j] == r) continue;
+                stamp[j] = r;
+                const int n = setid[find(recs[j].atom)];
+                if (n == r) continue;
+                if (counts[n]++ == 0) touched.push_back(n);
+            }
+        }
+        std::sort(touched.begin(), touched.end());  // np.unique is sorted
+        int mapto = r, maxmap = 0;
+        long long myarea = 0;
+        for (int n : touched) {
+            if (counts[n] > maxmap && !id_in_spare(n)) {
+                maxmap = counts[n];
+                mapto = n;
+                myarea = cache_area[r];
+            }
+        }
+        for (int n : touched) counts[n] = 0;
+        if (mapto != r) {  // regionmask[regionmask == r.label] = mapto
+            const int rr = find(rep[r]), rm = find(rep[mapto]);
+            uf[rr] = rm;
+            setid[rm] = mapto;
+            next[tail[mapto]] = head[r];
+            tail[mapto] = tail[r];
+            head[r] = 0;
+            info.merged++;
+        }
+        const int mt = lv[mapto];
+        if (cache_area[mapto] == (long long)maxsub[mt]) maxsub[mt] += (unsigned)myarea;  // :330-338
+        cache_area[mapto] += myarea;                                                     // :339
+    }
+    lut.assign(R + 1, 0);
+    for (int a = 1; a <= R; ++a) {
+        uint8_t v = lobemap[setid[find(a)]];  // :341
+        if (spare_label[v]) v = 0;            // :342
+        lut[a] = v;
+    }
+}
+
+}  // namespace
+
+int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spare_p, int n_spare, int skip_below) {
+    if (N <= 0 || H <= 0 || W <= 0) return LM_OK;
+    const Dims d{N, H, W};
+    const size_t nvox = d.nvox();
+    if (nvox >= 0x7fffffffull) {
+        set_error("volume too large for 32-bit voxel indices");
+        return LM_ERR_INVALID;
+    }
+    hipStream_t s = e->stream;
+    PostWorkspace& ws = e->post;
+    PostInfo& info = e->post_info;
+    info = PostInfo();
+    std::vector<int> spare(spare_p, spare_p + (spare_p ? n_spare : 0));
+    const size_t nb = rank_blocks(nvox);
+    LM_TRY(ws.parent.reserve(nvox * 4));
+    LM_TRY(ws.ids.reserve(nvox * 4));
+    LM_TRY(ws.rank.reserve(nvox * 4));
+    LM_TRY(ws.bgparent.reserve(nvox * 4));
+    LM_TRY(ws.blockcnt.reserve((nb + 2) * 4));
+    LM_TRY(ws.mapped.reserve(nvox));
+    LM_TRY(ws.bg.reserve(nvox));
+    LM_TRY(ws.out.reserve(nvox));
+    LM_TRY(ws.scalars.reserve(4096));
+    int* parent = ws.parent.as<int>();
+    int* ids = ws.ids.as<int>();
+    int* total_dev = ws.scalars.as<int>();
+    unsigned* count_dev = ws.scalars.as<unsigned>() + 1;
+    unsigned long long* best_dev = reinterpret_cast<unsigned long long*>(ws.scalars.as<char>() + 1024);
+
+    // ---- (1) skimage.measure.label (26-connected, multi-label), ids in raster order        utils.py:293
+    {
+        ProfScope ps(e, "post_ccl26_multilabel", (double)nvox * 13);
+        LM_K(ccl_label(lab, parent, d, true, s));
+    }
+    {
+        ProfScope ps(e, "post_rank_relabel", (double)nvox * 16);
+        LM_K(ccl_rank(parent, ws.rank.as<int>(), ids, ws.blockcnt.as<int>(), total_dev, nvox, s));
+    }
+    int R = 0;
+    LM_HIP(hipMemcpyAsync(&R, total_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+    LM_HIP(hipStreamSynchronize(s));
+    info.regions = R;
+    std::vector<uint8_t> lut(1, 0);
+    if (R > 0) {
+        // ---- (2) regionprops: area + label value                                           utils.py:298
+        LM_TRY(ws.area.reserve(((size_t)R + 1) * 4));
+        LM_TRY(ws.labval.reserve((size_t)R + 1));
+        LM_HIP(hipMemsetAsync(ws.area.p, 0, ((size_t)R + 1) * 4, s));
+        LM_HIP(hipMemsetAsync(ws.labval.p, 0, (size_t)R + 1, s));
+        {
+            ProfScope ps(e, "post_region_stats", (double)nvox * 5);
+            LM_K(region_stats(ids, lab, ws.area.as<int>(), ws.labval.as<uint8_t>(), nvox, s));
+        }
+        // ---- (3) boundary voxels between regions (the only voxels the merge loop can ever count)
+        unsigned cap = (unsigned)std::min<size_t>(nvox, std::max<size_t>(ws.recs.cap / sizeof(BoundaryRec), 1u << 20));
+        unsigned nrec = 0;
+        for (;;) {
+            LM_TRY(ws.recs.reserve((size_t)cap * sizeof(BoundaryRec)));
+            LM_HIP(hipMemsetAsync(count_dev, 0, sizeof(unsigned), s));
+            {
+                ProfScope ps(e, "post_boundary_records", (double)nvox * 4);
+                LM_K(boundary_records(ids, d, ws.recs.as<BoundaryRec>(), count_dev, cap, s));
+            }
+            LM_HIP(hipMemcpyAsync(&nrec, count_dev, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+            LM_HIP(hipStreamSynchronize(s));
+            if (nrec <= cap) break;
+            cap = nrec;  // rare: grow and redo
+        }
+        info.boundary_records = nrec;
+        std::vector<int> area((size_t)R + 1);
+        std::vector<uint8_t> lv((size_t)R + 1);
+        std::vector<BoundaryRec> recs(nrec);
+        LM_HIP(hipMemcpyAsync(area.data(), ws.area.p, ((size_t)R + 1) * 4, hipMemcpyDeviceToHost, s));
+        LM_HIP(hipMemcpyAsync(lv.data(), ws.labval.p, (size_t)R + 1, hipMemcpyDeviceToHost, s));
+        if (nrec) LM_HIP(hipMemcpyAsync(recs.data(), ws.recs.p, (size_t)nrec * sizeof(BoundaryRec), hipMemcpyDeviceToHost, s));
+        LM_HIP(hipStreamSynchronize(s));
+        // ---- (4) the sequential merge on the region graph                                  utils.py:299-342
+        const auto t0 = std::chrono::steady_clock::now();
+        replay_merge(R, area, lv, recs, spare, skip_below, lut, info);
+        info.host_replay_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    LM_TRY(ws.lut.reserve(lut.size()));
+    LM_HIP(hipMemcpyAsync(ws.lut.p, lut.data(), lut.size(), hipMemcpyHostToDevice, s));
+    uint8_t* mapped = ws.mapped.as<uint8_t>();
+    {
+        ProfScope ps(e, "post_apply_lut", (double)nvox * 5);
+        LM_K(apply_lut(ids, ws.lut.as<uint8_t>(), mapped, nvox, s));
+    }
+    // ---- (5) per label: keep the largest 26-connected component, fill holes, write          utils.py:344-356
+    {
+        ProfScope ps(e, "post_ccl26_mapped", (double)nvox * 13);
+        LM_K(ccl_label(mapped, parent, d, true, s));
+    }
+    {
+        ProfScope ps(e, "post_component_max", (double)nvox * 9);
+        LM_K(component_max(parent, mapped, ids /* reused: area per root */, best_dev, nvox, s));
+    }
+    unsigned long long best[256];
+    LM_HIP(hipMemcpyAsync(best, best_dev, sizeof best, hipMemcpyDeviceToHost, s));
+    LM_HIP(hipStreamSynchronize(s));
+    uint8_t* out = ws.out.as<uint8_t>();
+    LM_HIP(hipMemsetAsync(out, 0, nvox, s));
+    for (int label = 1; label < 256; ++label) {
+        if (!best[label]) continue;
+        const int keep_root = (int)(unsigned)(best[label] & 0xffffffffull);
+        LM_K(complement_of_component(parent, keep_root, ws.bg.as<uint8_t>(), nvox, s));
+        {
+            ProfScope ps(e, "post_ccl6_background", (double)nvox * 9);
+            LM_K(ccl_label(ws.bg.as<uint8_t>(), ws.bgparent.as<int>(), d, false, s));
+        }
+        if (N == 1)  // skimage.morphology.area_closing(area_threshold=64)                       utils.py:344-350
+            LM_K(flag_large_components(ws.bgparent.as<int>(), ids, 64, nvox, s));
+        else  // fill_voids.fill: background not 6-connected to a face of the volume             utils.py:352
+            LM_K(flag_face_components(ws.bgparent.as<int>(), ids, d, s));
+        {
+            ProfScope ps(e, "post_fill_write", (double)nvox * 13);
+            LM_K(fill_write(parent, keep_root, ws.bgparent.as<int>(), ids, (uint8_t)label, out, nvox, s));
+        }
+    }
+    LM_HIP(hipMemcpyAsync(lab, out, nvox, hipMemcpyDeviceToDevice, s));
+    return LM_OK;
+}
+
+// ------------------------------------------------------------------------------ LMInferer.apply
+namespace {
+
+int inference(lm_engine* e, int slot, const void* vol, int dtype, int n, int h, int w, int batch, int vol_post, bool have_pre, uint8_t* out) {
+    ApplyWorkspace& a = e->app;
+    constexpr int R = 256;  // mask.py:166 resolution=[256, 256]
+    LM_TRY(a.xf.reserve((size_t)n * R * R * 4));
+    LM_TRY(a.bbox.reserve((size_t)n * 16));
+    LM_TRY(a.labels.reserve((size_t)n * R * R));
+    if (!have_pre) {  // mask.py:166-168
+        BodyMaskParams bp{vol, dtype, n, h, w, a.bbox.as<int>(), nullptr};
+        const int esz = dtype == LM_I16 ? 2 : (dtype == LM_I32 ? 4 : 8);
+        {
+            ProfScope ps(e, "bodymask_bbox", (double)n * 128 * 128 * esz);
+            LM_K(launch_bodymask_bbox(bp, e->stream));
+        }
+        ResampleParams rp{vol, dtype, n, h, w, a.bbox.as<int>(), R, R, nullptr, a.xf.as<float>()};
+        {
+            ProfScope ps(e, "resample_norm", (double)n * h * w * esz + (double)n * R * R * 4);
+            LM_K(launch_resample_norm(rp, e->stream));
+        }
+    }
+    for (int b0 = 0; b0 < n; b0 += batch) {  // mask.py:173-187
+        const int b = std::min(batch, n - b0);
+        LM_TRY(forward(e, slot, a.xf.as<float>() + (size_t)b0 * R * R, b, R, R, a.labels.as<uint8_t>() + (size_t)b0 * R * R, nullptr));
+    }
+    if (vol_post) LM_TRY(postprocess(e, a.labels.as<uint8_t>(), n, R, R, nullptr, 0, 3));  // mask.py:191-194
+    ReshapeParams rs{a.labels.as<uint8_t>(), a.bbox.as<int>(), out, n, R, R, h, w};  // mask.py:196-202
+    {
+        ProfScope ps(e, "reshape_mask", (double)n * ((double)R * R + (double)h * w));
+        LM_K(launch_reshape_mask(rs, e->stream));
+    }
+    return LM_OK;
+}
+
+}  // namespace
+
+int apply_volume(lm_engine* e, int slot, int fill_slot, const void* vol, int dtype, int n, int h, int w, int batch, int vol_post,
+                 uint8_t* out) {
+    if (n <= 0) return LM_OK;
+    if (batch <= 0) batch = 20;
+    if (dtype != LM_I16 && dtype != LM_I32 && dtype != LM_I64) {
+        set_error("lm_apply: unsupported dtype code %d (integer HU volumes only)", dtype);
+        return LM_ERR_INVALID;
+    }
+    LM_TRY(inference(e, slot, vol, dtype, n, h, w, batch, vol_post, false, out));
+    if (fill_slot < 0) return LM_OK;
+    // ---- LTRCLobes_R231 fusion (mask.py:223-232); the reference recomputes the identical pre-processing, we reuse it
+    ApplyWorkspace& a = e->app;
+    const size_t nvox = (size_t)n * h * w;
+    LM_TRY(a.res_r.reserve(nvox));
+    LM_TRY(inference(e, fill_slot, vol, dtype, n, h, w, batch, vol_post, true, a.res_r.as<uint8_t>()));
+    LM_TRY(e->post.scalars.reserve(4096));
+    unsigned* mx_dev = e->post.scalars.as<unsigned>() + 2;
+    LM_K(volume_max(out, mx_dev, nvox, e->stream));
+    unsigned mx = 0;
+    LM_HIP(hipMemcpyAsync(&mx, mx_dev, sizeof mx, hipMemcpyDeviceToHost, e->stream));
+    LM_HIP(hipStreamSynchronize(e->stream));
+    const int spare = (int)((mx + 1) & 0xff);  // res_l.max() + 1 (uint8), mask.py:228
+    {
+        ProfScope ps(e, "fuse_labels", (double)nvox * 3);
+        LM_K(fuse_labels(out, a.res_r.as<uint8_t>(), (uint8_t)spare, nvox, e->stream));
+    }
+    return postprocess(e, out, n, h, w, &spare, 1, 3);  // mask.py:232
+}
+
+}  // namespace lm

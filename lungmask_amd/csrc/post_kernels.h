@@ -1,0 +1,51 @@
+// Launchers of the volume post-processing kernels (post_kernels.hip): 3-D
+// connected-component labelling and the voxel-level parts of
+// lungmask/utils.py:272-358 (postprocessing), :390-404
+// (keep_largest_connected_component), fill_voids.fill and mask.py:228-230 (fusion).
+#pragma once
+#include "lm_platform.h"
+
+namespace lm {
+
+struct Dims {
+    int N, H, W;
+    __host__ __device__ size_t nvox() const { return (size_t)N * H * W; }
+};
+
+// One boundary voxel: its atom (initial region id) and the distinct other atoms among its 6 neighbours.
+struct BoundaryRec {
+    int atom;
+    int nb[6];
+};
+
+// ---- connected components (union-find on an int32 parent volume; root = first voxel in raster order)
+// lab: u8 volume; foreground = non-zero; voxels are connected when adjacent AND equal.
+hipError_t ccl_label(const uint8_t* lab, int* parent, Dims d, bool conn26, hipStream_t s);
+// Dense ids in raster order of each component's first voxel (== skimage.measure.label numbering).
+// blockcnt: scratch of >= nblocks(nvox)+1 ints.  total_dev receives the number of components.
+size_t rank_blocks(size_t nvox);
+hipError_t ccl_rank(const int* parent, int* rank, int* ids, int* blockcnt, int* total_dev, size_t nvox, hipStream_t s);
+hipError_t region_stats(const int* ids, const uint8_t* lab, int* area, uint8_t* labval, size_t nvox, hipStream_t s);
+hipError_t boundary_records(const int* ids, Dims d, BoundaryRec* recs, unsigned* count_dev, unsigned cap, hipStream_t s);
+hipError_t apply_lut(const int* ids, const uint8_t* lut, uint8_t* out, size_t nvox, hipStream_t s);
+
+// ---- per-label largest component + hole filling
+// area_by_root[root] = component size (array of nvox ints, zeroed here); best[256] u64 = max over the
+// components of each label value of (area << 32 | root)  (largest area, highest root index on ties).
+hipError_t component_max(const int* parent, const uint8_t* lab, int* area_by_root, unsigned long long* best, size_t nvox, hipStream_t s);
+// bg[v] = (parent[v] != keep_root)
+hipError_t complement_of_component(const int* parent, int keep_root, uint8_t* bg, size_t nvox, hipStream_t s);
+// flags[root] = 1 for every bg component touching a face of the volume (flags: nvox ints, zeroed here).
+hipError_t flag_face_components(const int* bgparent, int* flags, Dims d, hipStream_t s);
+// N == 1 path (utils.py:344-350, area_closing(area_threshold=64)): flags[root] = 1 when the 2-D
+// 4-connected background component has area >= threshold.
+hipError_t flag_large_components(const int* bgparent, int* flags, int threshold, size_t nvox, hipStream_t s);
+// out[v] = label where v is in the kept component or in an unflagged background component.
+hipError_t fill_write(const int* parent, int keep_root, const int* bgparent, const int* flags, uint8_t label, uint8_t* out, size_t nvox,
+                      hipStream_t s);
+
+// ---- fusion (mask.py:228-230)
+hipError_t volume_max(const uint8_t* a, unsigned* max_dev, size_t nvox, hipStream_t s);
+hipError_t fuse_labels(uint8_t* res_l, const uint8_t* res_r, uint8_t spare, size_t nvox, hipStream_t s);
+
+}  // namespace lm

@@ -1,0 +1,397 @@
+// Volume post-processing kernels (integer/byte work, HBM-bound).
+//
+// Connected components: union-find on an int32 parent volume with atomicMin
+// hooking (root = smallest linear index = first voxel in raster order, which is
+// exactly the key skimage.measure.label numbers regions by).  26-connectivity
+// needs the 13 raster-earlier neighbours, 6-connectivity 3.  Stale (cached)
+// parent reads are harmless: parents only ever decrease along ancestor chains
+// and every hook is an L2 atomic that re-validates "was still a root".
+#include "post_kernels.h"
+
+namespace lm {
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int ITEMS = 16;  // consecutive voxels per thread in order-preserving passes
+constexpr int BLOCK_VOX = TPB * ITEMS;
+
+inline unsigned grid_for(size_t n, int per_block = TPB, unsigned cap = 256 * 32) {
+    size_t b = (n + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    return (unsigned)std::min<size_t>(b, cap);
+}
+
+__device__ __forceinline__ int find_root(const int* P, int x) {
+    const volatile int* vp = P;
+    int p;
+    while ((p = vp[x]) != x) x = p;
+    return x;
+}
+
+__device__ __forceinline__ void unite(int* P, int a, int b) {
+    for (;;) {
+        a = find_root(P, a);
+        b = find_root(P, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(&P[a], b);
+        if (old == a) return;  // a was still a root: hooked under b
+        a = old;               // a had been re-parented meanwhile: keep joining its (old) parent with b
+    }
+}
+
+__global__ __launch_bounds__(TPB) void ccl_init_kernel(const uint8_t* __restrict__ lab, int* __restrict__ P, size_t nvox) {
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x)
+        P[v] = lab[v] ? (int)v : -1;
+}
+
+template <bool C26>
+__global__ __launch_bounds__(TPB) void ccl_merge_kernel(const uint8_t* __restrict__ lab, int* P, Dims d) {
+    const size_t nvox = d.nvox();
+    const size_t HW = (size_t)d.H * d.W;
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x) {
+        const uint8_t L = lab[v];
+        if (!L) continue;
+        const int x = (int)(v % d.W), y = (int)((v / d.W) % d.H), z = (int)(v / HW);
+        if (x > 0 && lab[v - 1] == L) unite(P, (int)v, (int)(v - 1));
+        if (y > 0) {
+            const size_t u = v - d.W;
+            if (lab[u] == L) unite(P, (int)v, (int)u);
+            if (C26) {
+                if (x > 0 && lab[u - 1] == L) unite(P, (int)v, (int)(u - 1));
+                if (x + 1 < d.W && lab[u + 1] == L) unite(P, (int)v, (int)(u + 1));
+            }
+        }
+        if (z > 0) {
+            const size_t c = v - HW;
+            if (lab[c] == L) unite(P, (int)v, (int)c);
+            if (C26) {
+                if (x > 0 && lab[c - 1] == L) unite(P, (int)v, (int)(c - 1));
+                if (x + 1 < d.W && lab[c + 1] == L) unite(P, (int)v, (int)(c + 1));
+                if (y > 0) {
+                    const size_t u = c - d.W;
+                    if (lab[u] == L) unite(P, (int)v, (int)u);
+                    if (x > 0 && lab[u - 1] == L) unite(P, (int)v, (int)(u - 1));
+                    if (x + 1 < d.W && lab[u + 1] == L) unite(P, (int)v, (int)(u + 1));
+                }
+                if (y + 1 < d.H) {
+                    const size_t u = c + d.W;
+                    if (lab[u] == L) unite(P, (int)v, (int)u);
+                    if (x > 0 && lab[u - 1] == L) unite(P, (int)v, (int)(u - 1));
+                    if (x + 1 < d.W && lab[u + 1] == L) unite(P, (int)v, (int)(u + 1));
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(TPB) void ccl_flatten_kernel(int* P, size_t nvox) {
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x) {
+        if (P[v] >= 0) P[v] = find_root(P, (int)v);
+    }
+}
+
+// ---- dense ids in raster order ------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void count_roots_kernel(const int* __restrict__ P, int* __restrict__ blockcnt, size_t nvox) {
+    __shared__ int total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    const size_t base = ((size_t)blockIdx.x * TPB + threadIdx.x) * ITEMS;
+    int c = 0;
+    for (int i = 0; i < ITEMS; ++i) {
+        const size_t v = base + i;
+        if (v < nvox && P[v] == (int)v) ++c;
+    }
+    if (c) atomicAdd(&total, c);
+    __syncthreads();
+    if (threadIdx.x == 0) blockcnt[blockIdx.x] = total;
+}
+
+// exclusive scan of blockcnt[0..nb) in place by ONE 1024-thread block; blockcnt[nb] and *total_dev get the sum
+__global__ __launch_bounds__(1024) void scan_blockcnt_kernel(int* blockcnt, int nb, int* total_dev) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int chunk = (nb + 1023) / 1024;
+    const int lo = t * chunk, hi = min(nb, lo + chunk);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += blockcnt[i];
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int add = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    int run = part[t] - s;  // exclusive prefix of this thread's chunk
+    for (int i = lo; i < hi; ++i) {
+        const int c = blockcnt[i];
+        blockcnt[i] = run;
+        run += c;
+    }
+    if (t == 1023) {
+        blockcnt[nb] = part[1023];
+        *total_dev = part[1023];
+    }
+}
+
+__global__ __launch_bounds__(TPB) void assign_rank_kernel(const int* __restrict__ P, int* __restrict__ rank, const int* __restrict__ blockoff, size_t nvox) {
+    __shared__ int part[TPB];
+    const int t = threadIdx.x;
+    const size_t base = ((size_t)blockIdx.x * TPB + t) * ITEMS;
+    int c = 0;
+    for (int i = 0; i < ITEMS; ++i) {
+        const size_t v = base + i;
+        if (v < nvox && P[v] == (int)v) ++c;
+    }
+    part[t] = c;
+    __syncthreads();
+    for (int off = 1; off < TPB; off <<= 1) {
+        const int add = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    int id = blockoff[blockIdx.x] + part[t] - c;  // ids are 1-based: pre-increment below
+    for (int i = 0; i < ITEMS; ++i) {
+        const size_t v = base + i;
+        if (v < nvox && P[v] == (int)v) rank[v] = ++id;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void relabel_kernel(const int* __restrict__ P, const int* __restrict__ rank, int* __restrict__ ids, size_t nvox) {
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x) {
+        const int r = P[v];
+        ids[v] = r >= 0 ? rank[r] : 0;
+    }
+}
+
+// ---- per-region statistics ----------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void region_stats_kernel(const int* __restrict__ ids, const uint8_t* __restrict__ lab, int* area,
+                                                           uint8_t* labval, size_t nvox) {
+    const size_t nchunks = (nvox + ITEMS - 1) / ITEMS;
+    for (size_t ch = (size_t)blockIdx.x * blockDim.x + threadIdx.x; ch < nchunks; ch += (size_t)gridDim.x * blockDim.x) {
+        const size_t base = ch * ITEMS;
+        int cur = 0, cnt = 0;
+        for (int i = 0; i < ITEMS; ++i) {
+            const size_t v = base + i;
+            const int id = v < nvox ? ids[v] : 0;
+            if (id != cur) {
+                if (cur) atomicAdd(&area[cur], cnt);
+                cur = id;
+                cnt = 0;
+                if (id) labval[id] = lab[v];
+            }
+            ++cnt;
+        }
+        if (cur) atomicAdd(&area[cur], cnt);
+    }
+}
+
+__global__ __launch_bounds__(TPB) void boundary_records_kernel(const int* __restrict__ ids, Dims d, BoundaryRec* recs, unsigned* count, unsigned cap) {
+    const size_t nvox = d.nvox();
+    const size_t HW = (size_t)d.H * d.W;
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x) {
+        const int a = ids[v];
+        if (!a) continue;
+        const int x = (int)(v % d.W), y = (int)((v / d.W) % d.H), z = (int)(v / HW);
+        int nb[6];
+        int k = 0;
+        auto add = [&](int b) {
+            if (b == 0 || b == a) return;
+            for (int i = 0; i < k; ++i)
+                if (nb[i] == b) return;
+            nb[k++] = b;
+        };
+        if (x > 0) add(ids[v - 1]);
+        if (x + 1 < d.W) add(ids[v + 1]);
+        if (y > 0) add(ids[v - d.W]);
+        if (y + 1 < d.H) add(ids[v + d.W]);
+        if (z > 0) add(ids[v - HW]);
+        if (z + 1 < d.N) add(ids[v + HW]);
+        if (k) {
+            const unsigned slot = atomicAdd(count, 1u);
+            if (slot < cap) {
+                BoundaryRec r;
+                r.atom = a;
+                for (int i = 0; i < 6; ++i) r.nb[i] = i < k ? nb[i] : 0;
+                recs[slot] = r;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(TPB) void apply_lut_kernel(const int* __restrict__ ids, const uint8_t* __restrict__ lut, uint8_t* __restrict__ out, size_t nvox) {
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x) out[v] = lut[ids[v]];
+}
+
+// ---- largest component per label ----------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void area_by_root_kernel(const int* __restrict__ P, int* area_by_root, size_t nvox) {
+    const size_t nchunks = (nvox + ITEMS - 1) / ITEMS;
+    for (size_t ch = (size_t)blockIdx.x * blockDim.x + threadIdx.x; ch < nchunks; ch += (size_t)gridDim.x * blockDim.x) {
+        const size_t base = ch * ITEMS;
+        int cur = -1, cnt = 0;
+        for (int i = 0; i < ITEMS; ++i) {
+            const size_t v = base + i;
+            const int r = v < nvox ? P[v] : -1;
+            if (r != cur) {
+                if (cur >= 0) atomicAdd(&area_by_root[cur], cnt);
+                cur = r;
+                cnt = 0;
+            }
+            ++cnt;
+        }
+        if (cur >= 0) atomicAdd(&area_by_root[cur], cnt);
+    }
+}
+
+__global__ __launch_bounds__(TPB) void label_max_kernel(const int* __restrict__ P, const uint8_t* __restrict__ lab, const int* __restrict__ area_by_root,
+                                                        unsigned long long* best, size_t nvox) {
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x) {
+        if (P[v] == (int)v) {
+            const unsigned long long key = ((unsigned long long)(unsigned)area_by_root[v] << 32) | (unsigned long long)(unsigned)v;
+            atomicMax(&best[lab[v]], key);
+        }
+    }
+}
+
+__global__ __launch_bounds__(TPB) void complement_kernel(const int* __restrict__ P, int keep_root, uint8_t* __restrict__ bg, size_t nvox) {
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x) bg[v] = (P[v] != keep_root) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(TPB) void flag_faces_kernel(const int* __restrict__ BP, int* flags, Dims d) {
+    const size_t nvox = d.nvox();
+    const size_t HW = (size_t)d.H * d.W;
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(v % d.W), y = (int)((v / d.W) % d.H), z = (int)(v / HW);
+        if (x == 0 || y == 0 || z == 0 || x == d.W - 1 || y == d.H - 1 || z == d.N - 1) {
+            const int r = BP[v];
+            if (r >= 0) flags[r] = 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(TPB) void threshold_roots_kernel(const int* __restrict__ BP, int* flags, int threshold, size_t nvox) {
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x)
+        if (BP[v] == (int)v) flags[v] = flags[v] >= threshold ? 1 : 0;
+}
+
+__global__ __launch_bounds__(TPB) void fill_write_kernel(const int* __restrict__ P, int keep_root, const int* __restrict__ BP, const int* __restrict__ flags,
+                                                         uint8_t label, uint8_t* out, size_t nvox) {
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x) {
+        bool on = P[v] == keep_root;
+        if (!on) {
+            const int r = BP[v];
+            on = r >= 0 && flags[r] == 0;
+        }
+        if (on) out[v] = label;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void volume_max_kernel(const uint8_t* __restrict__ a, unsigned* mx, size_t nvox) {
+    unsigned m = 0;
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x) m = max(m, (unsigned)a[v]);
+    if (m) atomicMax(mx, m);
+}
+
+__global__ __launch_bounds__(TPB) void fuse_kernel(uint8_t* res_l, const uint8_t* __restrict__ res_r, uint8_t spare, size_t nvox) {
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x) {
+        uint8_t l = res_l[v];
+        const uint8_t r = res_r[v];
+        if (l == 0 && r > 0) l = spare;  // mask.py:229
+        if (r == 0) l = 0;               // mask.py:230
+        res_l[v] = l;
+    }
+}
+
+}  // namespace
+
+hipError_t ccl_label(const uint8_t* lab, int* parent, Dims d, bool conn26, hipStream_t s) {
+    const size_t n = d.nvox();
+    if (n == 0) return hipSuccess;
+    LM_LAUNCH(ccl_init_kernel, dim3(grid_for(n)), dim3(TPB), 0, s, lab, parent, n);
+    if (conn26)
+        LM_LAUNCH((ccl_merge_kernel<true>), dim3(grid_for(n)), dim3(TPB), 0, s, lab, parent, d);
+    else
+        LM_LAUNCH((ccl_merge_kernel<false>), dim3(grid_for(n)), dim3(TPB), 0, s, lab, parent, d);
+    LM_LAUNCH(ccl_flatten_kernel, dim3(grid_for(n)), dim3(TPB), 0, s, parent, n);
+    return hipGetLastError();
+}
+
+size_t rank_blocks(size_t nvox) { return (nvox + BLOCK_VOX - 1) / BLOCK_VOX; }
+
+hipError_t ccl_rank(const int* parent, int* rank, int* ids, int* blockcnt, int* total_dev, size_t nvox, hipStream_t s) {
+    const size_t nb = rank_blocks(nvox);
+    if (nb == 0) return hipSuccess;
+    LM_LAUNCH(count_roots_kernel, dim3((unsigned)nb), dim3(TPB), 0, s, parent, blockcnt, nvox);
+    LM_LAUNCH(scan_blockcnt_kernel, dim3(1), dim3(1024), 0, s, blockcnt, (int)nb, total_dev);
+    LM_LAUNCH(assign_rank_kernel, dim3((unsigned)nb), dim3(TPB), 0, s, parent, rank, (const int*)blockcnt, nvox);
+    LM_LAUNCH(relabel_kernel, dim3(grid_for(nvox)), dim3(TPB), 0, s, parent, (const int*)rank, ids, nvox);
+    return hipGetLastError();
+}
+
+hipError_t region_stats(const int* ids, const uint8_t* lab, int* area, uint8_t* labval, size_t nvox, hipStream_t s) {
+    LM_LAUNCH(region_stats_kernel, dim3(grid_for((nvox + ITEMS - 1) / ITEMS)), dim3(TPB), 0, s, ids, lab, area, labval, nvox);
+    return hipGetLastError();
+}
+
+hipError_t boundary_records(const int* ids, Dims d, BoundaryRec* recs, unsigned* count_dev, unsigned cap, hipStream_t s) {
+    LM_LAUNCH(boundary_records_kernel, dim3(grid_for(d.nvox())), dim3(TPB), 0, s, ids, d, recs, count_dev, cap);
+    return hipGetLastError();
+}
+
+hipError_t apply_lut(const int* ids, const uint8_t* lut, uint8_t* out, size_t nvox, hipStream_t s) {
+    LM_LAUNCH(apply_lut_kernel, dim3(grid_for(nvox)), dim3(TPB), 0, s, ids, lut, out, nvox);
+    return hipGetLastError();
+}
+
+hipError_t component_max(const int* parent, const uint8_t* lab, int* area_by_root, unsigned long long* best, size_t nvox, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(area_by_root, 0, nvox * sizeof(int), s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(best, 0, 256 * sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    LM_LAUNCH(area_by_root_kernel, dim3(grid_for((nvox + ITEMS - 1) / ITEMS)), dim3(TPB), 0, s, parent, area_by_root, nvox);
+    LM_LAUNCH(label_max_kernel, dim3(grid_for(nvox)), dim3(TPB), 0, s, parent, lab, (const int*)area_by_root, best, nvox);
+    return hipGetLastError();
+}
+
+hipError_t complement_of_component(const int* parent, int keep_root, uint8_t* bg, size_t nvox, hipStream_t s) {
+    LM_LAUNCH(complement_kernel, dim3(grid_for(nvox)), dim3(TPB), 0, s, parent, keep_root, bg, nvox);
+    return hipGetLastError();
+}
+
+hipError_t flag_face_components(const int* bgparent, int* flags, Dims d, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(flags, 0, d.nvox() * sizeof(int), s);
+    if (e != hipSuccess) return e;
+    LM_LAUNCH(flag_faces_kernel, dim3(grid_for(d.nvox())), dim3(TPB), 0, s, bgparent, flags, d);
+    return hipGetLastError();
+}
+
+hipError_t flag_large_components(const int* bgparent, int* flags, int threshold, size_t nvox, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(flags, 0, nvox * sizeof(int), s);
+    if (e != hipSuccess) return e;
+    LM_LAUNCH(area_by_root_kernel, dim3(grid_for((nvox + ITEMS - 1) / ITEMS)), dim3(TPB), 0, s, bgparent, flags, nvox);
+    LM_LAUNCH(threshold_roots_kernel, dim3(grid_for(nvox)), dim3(TPB), 0, s, bgparent, flags, threshold, nvox);
+    return hipGetLastError();
+}
+
+hipError_t fill_write(const int* parent, int keep_root, const int* bgparent, const int* flags, uint8_t label, uint8_t* out, size_t nvox,
+                      hipStream_t s) {
+    LM_LAUNCH(fill_write_kernel, dim3(grid_for(nvox)), dim3(TPB), 0, s, parent, keep_root, bgparent, flags, label, out, nvox);
+    return hipGetLastError();
+}
+
+hipError_t volume_max(const uint8_t* a, unsigned* max_dev, size_t nvox, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(max_dev, 0, sizeof(unsigned), s);
+    if (e != hipSuccess) return e;
+    LM_LAUNCH(volume_max_kernel, dim3(grid_for(nvox)), dim3(TPB), 0, s, a, max_dev, nvox);
+    return hipGetLastError();
+}
+
+hipError_t fuse_labels(uint8_t* res_l, const uint8_t* res_r, uint8_t spare, size_t nvox, hipStream_t s) {
+    LM_LAUNCH(fuse_kernel, dim3(grid_for(nvox)), dim3(TPB), 0, s, res_l, res_r, spare, nvox);
+    return hipGetLastError();
+}
+
+}  // namespace lm

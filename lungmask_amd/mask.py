@@ -1,0 +1,132 @@
+"""Drop-in for `lungmask/mask.py` (reference v0.2.20): same names, arguments and
+error behaviour; everything below `LMInferer.apply` runs in liblungmask_hip.so
+on an MI355X (one C-ABI call, volume device-resident).
+
+Reference lines are cited per method.  PyTorch is used only to deserialise the
+`.pth` state_dict (mask.py:48-54); there is no CPU compute path.
+"""
+from __future__ import annotations
+
+import os
+import warnings
+from typing import Optional, Union
+
+import numpy as np
+
+from . import _native
+from .logger import logger
+
+warnings.filterwarnings("ignore", category=UserWarning)  # mask.py:18
+
+# mask.py:22-35
+MODEL_URLS = {
+    "R231": ("https://github.com/JoHof/lungmask/releases/download/v0.0/unet_r231-d5d2fc3d.pth", 3),
+    "LTRCLobes": ("https://github.com/JoHof/lungmask/releases/download/v0.0/unet_ltrclobes-3a07043d.pth", 6),
+    "R231CovidWeb": ("https://github.com/JoHof/lungmask/releases/download/v0.0/unet_r231covid-0de78a7e.pth", 3),
+}
+
+
+def get_model(modelname: str, modelpath: Optional[str] = None):
+    """mask.py:38-68 -- returns the *state_dict* (the network itself lives in HBM).
+    `modelpath` overrides `modelname`; `$LUNGMASK_WEIGHTS_DIR/<basename of the url>` is
+    tried before the network download."""
+    import torch
+
+    if modelpath is None:
+        model_url, _ = MODEL_URLS[modelname]
+        local = os.path.join(os.environ.get("LUNGMASK_WEIGHTS_DIR", ""), os.path.basename(model_url))
+        if os.environ.get("LUNGMASK_WEIGHTS_DIR") and os.path.exists(local):
+            state_dict = torch.load(local, map_location=torch.device("cpu"))
+        else:
+            state_dict = torch.hub.load_state_dict_from_url(model_url, progress=True, map_location=torch.device("cpu"))
+    else:
+        state_dict = torch.load(modelpath, map_location=torch.device("cpu"))
+    return state_dict
+
+
+class LMInferer:
+    """mask.py:71-232."""
+
+    def __init__(
+        self,
+        modelname: str = "R231",
+        modelpath: Optional[str] = None,
+        fillmodel: Optional[str] = None,
+        fillmodel_path: Optional[str] = None,
+        force_cpu: bool = False,
+        batch_size: int = 20,
+        volume_postprocessing: bool = True,
+        tqdm_disable: bool = False,
+        device_id: int = 0,
+    ):
+        assert modelname in MODEL_URLS, "Modelname not found. Please choose from: {}".format(MODEL_URLS.keys())  # mask.py:95-97
+        if fillmodel is not None:
+            assert fillmodel in MODEL_URLS, "Modelname not found. Please choose from: {}".format(MODEL_URLS.keys())
+        if modelpath is not None:  # mask.py:104-107
+            modelname = os.path.basename(modelpath)
+        if fillmodel_path is not None:
+            fillmodel = os.path.basename(fillmodel_path)
+        self.fillmodel = fillmodel
+        self.modelname = modelname
+        self.force_cpu = force_cpu
+        self.batch_size = batch_size
+        self.volume_postprocessing = volume_postprocessing
+        self.tqdm_disable = tqdm_disable
+        if force_cpu:
+            # mask.py:118-134 would silently fall back to torch-CPU; this engine has no CPU path by design.
+            raise RuntimeError("lungmask_amd is an MI355X-only engine: force_cpu=True is not available (use the reference package for CPU)")
+        self.engine = _native.Engine(device_id)
+        self.engine.load_state_dict(0, get_model(self.modelname, modelpath))
+        self.fill_slot = -1
+        if self.fillmodel is not None:  # mask.py:136-139
+            self.engine.load_state_dict(1, get_model(self.fillmodel, fillmodel_path))
+            self.fill_slot = 1
+
+    def apply(self, image) -> np.ndarray:
+        """mask.py:212-232 (+ _inference :141-210).  `image`: numpy volume [n,h,w] or SimpleITK image."""
+        numpy_mode = isinstance(image, np.ndarray)
+        curr_orient = "LPS"
+        if numpy_mode:
+            inimg_raw = image
+        else:  # mask.py:156-164
+            import SimpleITK as sitk
+
+            curr_orient = sitk.DICOMOrientImageFilter_GetOrientationFromDirectionCosines(image.GetDirection())
+            if curr_orient != "LPS":
+                image = sitk.DICOMOrient(image, "LPS")
+            inimg_raw = sitk.GetArrayFromImage(image)
+        if inimg_raw.dtype.kind == "f" or inimg_raw.dtype not in _native.LM_DTYPES:
+            # integer HU volumes are what CT readers produce; floats are rounded the way CT data arrives
+            if inimg_raw.dtype.kind in "iu":
+                inimg_raw = inimg_raw.astype(np.int32)
+            else:
+                raise TypeError(f"lungmask_amd: unsupported volume dtype {inimg_raw.dtype} (integer HU expected)")
+        if self.fillmodel is not None:
+            logger.info(f"Apply: {self.modelname}")
+            logger.info(f"Apply: {self.fillmodel}")
+            logger.info("Fusing results... this may take up to several minutes!")
+        outmask = self.engine.apply(0, inimg_raw, fill_slot=self.fill_slot, batch_size=self.batch_size,
+                                    volume_postprocessing=self.volume_postprocessing)
+        if not numpy_mode and curr_orient != "LPS":  # mask.py:204-208
+            import SimpleITK as sitk
+
+            outmask = sitk.GetArrayFromImage(sitk.DICOMOrient(sitk.GetImageFromArray(outmask), curr_orient))
+        return outmask.astype(np.uint8)
+
+
+def apply(image, model=None, force_cpu=False, batch_size=20, volume_postprocessing=True, tqdm_disable=False):
+    """Deprecated shim, mask.py:235-255.  `model` may be a state_dict."""
+    warnings.warn("The function `apply` will be removed in a future version. Please use the LMInferer class!", DeprecationWarning)
+    inferer = LMInferer(force_cpu=force_cpu, batch_size=batch_size, volume_postprocessing=volume_postprocessing, tqdm_disable=tqdm_disable)
+    if model is not None:
+        sd = model.state_dict() if hasattr(model, "state_dict") else model
+        inferer.engine.load_state_dict(0, sd)
+    return inferer.apply(image)
+
+
+def apply_fused(image, basemodel="LTRCLobes", fillmodel="R231", force_cpu=False, batch_size=20, volume_postprocessing=True, tqdm_disable=False):
+    """Deprecated shim, mask.py:258-279."""
+    warnings.warn("The function `apply_fused` will be removed in a future version. Please use the LMInferer class!", DeprecationWarning)
+    inferer = LMInferer(modelname=basemodel, force_cpu=force_cpu, fillmodel=fillmodel, batch_size=batch_size,
+                        volume_postprocessing=volume_postprocessing, tqdm_disable=tqdm_disable)
+    return inferer.apply(image)

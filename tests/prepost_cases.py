@@ -33,3 +33,46 @@ def check_reshape(eng):
         out = eng.reshape_mask(g[f"rs{i}_mask"], g[f"rs{i}_box"], tuple(int(x) for x in g[f"rs{i}_osz"]))[0]
         assert np.array_equal(out, g[f"rs{i}_out"]), i
     return int(g["n_rs"])
+
+
+def check_postprocess(eng, max_voxels=None):
+    g = np.load(GOLD)
+    n_checked = 0
+    for i in range(int(g["n_post"])):
+        lab = g[f"post{i}_lab"]
+        if max_voxels and lab.size > max_voxels:
+            continue
+        spare = [int(x) for x in g[f"post{i}_spare"]]
+        out = eng.postprocess(lab, spare=spare, skip_below=int(g[f"post{i}_skip"]))
+        assert np.array_equal(out, g[f"post{i}_out"]), (i, lab.shape, spare, int((out != g[f"post{i}_out"]).sum()))
+        n_checked += 1
+    return n_checked
+
+
+def check_postprocess_random(eng, seeds, shape=(7, 40, 36), nlab=4):
+    """Differential test against the oracle on seeded random blob volumes."""
+    from oracle.make_golden import random_blobs
+
+    for seed in seeds:
+        rng = np.random.default_rng(seed)
+        lab = random_blobs(rng, shape, nlab, 18, 0.3)
+        for spare, skip in (((), 3), ((nlab,), 3), ((), 1)):
+            out = eng.postprocess(lab, spare=spare, skip_below=skip)
+            ref = po.postprocessing(lab.copy(), spare=list(spare), skip_below=skip)
+            assert np.array_equal(out, ref), (seed, spare, skip, int((out != ref).sum()))
+
+
+def check_fuse(eng):
+    from oracle.make_golden import random_blobs
+
+    rng = np.random.default_rng(11)
+    res_l = random_blobs(rng, (6, 40, 40), 5, 20, 0.3)
+    res_r = (random_blobs(rng, (6, 40, 40), 2, 14, 0.35)).astype(np.uint8)
+    fused, spare = eng.fuse(res_l, res_r)
+    ref = res_l.copy()
+    sv = ref.max() + 1
+    ref[np.logical_and(ref == 0, res_r > 0)] = sv
+    ref[res_r == 0] = 0
+    assert spare == int(sv) and np.array_equal(fused, ref)
+    out = eng.postprocess(fused, spare=[spare])
+    assert np.array_equal(out, po.fuse(res_l, res_r))

@@ -1,0 +1,111 @@
+"""End-to-end parity of the hot path `LMInferer.apply` on the GPU (lm_apply_host)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import prepost_oracle as po
+from oracle import unet_oracle as uo
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def oracle_forward(sd, x):
+    with torch.inference_mode():
+        logp = uo.forward(sd, torch.from_numpy(x))
+    srt = torch.sort(logp, dim=1, descending=True)[0]
+    return logp.argmax(1).numpy().astype(np.uint8), (srt[:, 0] - srt[:, 1]).numpy()
+
+
+def gpu_labels(eng, slot, x):
+    return eng.forward(slot, x, want_logp=False)[0]
+
+
+def run_case(eng, sd, vol, batch):
+    """Returns (#forward label mismatches vs oracle). Asserts:
+    * every forward mismatch sits on a near-tie pixel of the oracle (margin < 2*TOL);
+    * lm_apply == oracle pre -> [engine argmax labels] -> oracle post -> oracle un-crop, bit for bit;
+    * when the forward has no mismatch, lm_apply == the pure oracle pipeline bit for bit."""
+    eng.load_state_dict(0, sd)
+    out = eng.apply(0, vol, batch_size=batch)
+    assert out.dtype == np.uint8 and out.shape == vol.shape
+    xs, boxes = po.preprocess(vol, [256, 256])
+    x = po.normalise(xs)[:, None]
+    ref_lab, margin = oracle_forward(sd, x)
+    lab = gpu_labels(eng, 0, x)
+    bad = lab != ref_lab
+    assert not np.any(bad & (margin > 2 * TOL)), int(bad.sum())
+    post = po.postprocessing(lab.copy())
+    expect = np.asarray([po.reshape_mask(post[i], boxes[i], vol.shape[1:]) for i in range(len(post))], dtype=np.uint8)
+    assert np.array_equal(out, expect), int((out != expect).sum())
+    if not bad.any():
+        pure = po.inference(vol, lambda xb: oracle_forward(sd, xb)[0], batch_size=batch)
+        assert np.array_equal(out, pure)
+    return int(bad.sum())
+
+
+def test_apply_r231_phantom(gpu_engine):
+    vol = po.phantom(6, 512, 512)
+    run_case(gpu_engine, uo.synthetic_state_dict(3), vol, batch=4)  # 6 slices, batch 4: ragged last batch
+
+
+def test_apply_ltrclobes_phantom_odd_shape(gpu_engine):
+    vol = po.phantom(5, 300, 420, seed=5)
+    run_case(gpu_engine, uo.synthetic_state_dict(6), vol, batch=20)
+
+
+def test_apply_without_volume_postprocessing(gpu_engine):
+    sd = uo.synthetic_state_dict(3)
+    gpu_engine.load_state_dict(0, sd)
+    vol = po.phantom(3, 512, 512, seed=8)
+    out = gpu_engine.apply(0, vol, volume_postprocessing=False)
+    xs, boxes = po.preprocess(vol, [256, 256])
+    lab = gpu_labels(gpu_engine, 0, po.normalise(xs)[:, None])
+    expect = np.asarray([po.reshape_mask(lab[i], boxes[i], vol.shape[1:]) for i in range(len(lab))], dtype=np.uint8)
+    assert np.array_equal(out, expect)
+
+
+def test_apply_fused_ltrclobes_r231(gpu_engine):
+    """mask.py:223-232 fused mode: two forwards + fusion + full-resolution post-processing."""
+    sd_l, sd_r = uo.synthetic_state_dict(6), uo.synthetic_state_dict(3)
+    gpu_engine.load_state_dict(0, sd_l)
+    gpu_engine.load_state_dict(1, sd_r)
+    vol = po.phantom(4, 256, 256, seed=21)
+    out = gpu_engine.apply(0, vol, fill_slot=1)
+    xs, boxes = po.preprocess(vol, [256, 256])
+    x = po.normalise(xs)[:, None]
+
+    def one(slot):
+        lab = gpu_labels(gpu_engine, slot, x)
+        post = po.postprocessing(lab.copy())
+        return np.asarray([po.reshape_mask(post[i], boxes[i], vol.shape[1:]) for i in range(len(post))], dtype=np.uint8)
+
+    expect = po.fuse(one(0), one(1))
+    assert np.array_equal(out, expect), int((out != expect).sum())
+
+
+def test_lminferer_dropin_api(gpu_engine, tmp_path):
+    """The reference's own API surface (mask.py:72-82, :212): LMInferer(modelpath=...).apply(ndarray)."""
+    from lungmask_amd import LMInferer
+
+    p = tmp_path / "unet_synth.pth"
+    sd = uo.synthetic_state_dict(3)
+    torch.save(sd, p)
+    with pytest.raises(AssertionError):
+        LMInferer(modelname="nope")  # mask.py:95-97
+    inferer = LMInferer(modelname="LTRCLobes", modelpath=str(p), tqdm_disable=True)  # path overrides name (tests/test_mask.py:38-47)
+    vol = po.phantom(3, 512, 512, seed=4)
+    res = inferer.apply(vol)
+    assert res.dtype == np.uint8 and res.shape == vol.shape and res.max() <= 2
+    gpu_engine.load_state_dict(0, sd)
+    assert np.array_equal(res, gpu_engine.apply(0, vol))
+
+
+def test_real_weights_golden_counts_if_available(gpu_engine):
+    """tests/test_mask.py:30-36 golden voxel counts -- needs the pretrained .pth (no network here)."""
+    wd = os.environ.get("LUNGMASK_WEIGHTS_DIR")
+    if not wd or not os.path.exists(os.path.join(wd, "unet_r231-d5d2fc3d.pth")):
+        pytest.skip("pretrained weights not available offline")
+    pytest.skip("fixture DICOM not shipped; see INTEGRATION.md")

@@ -9,3 +9,15 @@ def test_preprocess_emulated_bit_exact(emu_engine):
 
 def test_reshape_mask_emulated_bit_exact(emu_engine):
     assert cases.check_reshape(emu_engine) >= 10
+
+
+def test_postprocessing_emulated_bit_exact(emu_engine):
+    assert cases.check_postprocess(emu_engine) >= 20
+
+
+def test_postprocessing_emulated_random_differential(emu_engine):
+    cases.check_postprocess_random(emu_engine, seeds=range(4))
+
+
+def test_fusion_emulated(emu_engine):
+    cases.check_fuse(emu_engine)
