@@ -32,15 +32,21 @@ def cpu_baseline(n_sample, sd):
     from oracle import prepost_oracle as po
     from oracle import unet_oracle as uo
 
-    cores = os.cpu_count() or 1
+    # torch's intra-op pool degrades badly beyond a few dozen threads at batch 1; use what actually helps
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     z0 = 150 - n_sample // 2
     vol = po.phantom(300, 512, 512, z0=z0, z1=z0 + n_sample)
+    t_nn = [0.0]
 
     def predict(xb):
-        return uo.predict_labels(sd, torch.from_numpy(np.ascontiguousarray(xb)))
+        t = time.perf_counter()
+        r = uo.predict_labels(sd, torch.from_numpy(np.ascontiguousarray(xb)))
+        t_nn[0] += time.perf_counter() - t
+        return r
 
     predict(np.zeros((1, 1, 256, 256), np.float32))  # warm-up
+    t_nn[0] = 0.0
     t = time.perf_counter()
     po.inference(vol, predict, batch_size=1)
     dt = time.perf_counter() - t
@@ -49,7 +55,8 @@ def cpu_baseline(n_sample, sd):
         "unit": "slices/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{n_sample} central slices (z={z0}..{z0 + n_sample - 1}) of the 512x512x300 phantom, batch 1, torch-CPU fp32 forward + scipy pre/post, {dt:.1f} s",
+        "sample": f"{n_sample} central slices (z={z0}..{z0 + n_sample - 1}) of the 512x512x300 phantom, batch 1 (what --cpu forces), "
+                  f"torch-CPU fp32 forward on {cores} threads ({t_nn[0]:.1f} s) + single-threaded scipy pre/post ({dt - t_nn[0]:.1f} s), {dt:.1f} s total",
     }
 
 
