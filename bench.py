@@ -24,6 +24,21 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP3
 FLOP_PER_SLICE = 96.200556544e9  # R231, SURVEY.md Appendix A (algorithmic, 256x256)
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this same
+    command (tools/summarize_prof.py -> profiles/rNN_pmc.json); None when no summary is present."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    for k, v in d.get("kernels", {}).items():
+        if kernel_substr in k and "hbm_bytes_per_launch_corrected" in v:
+            return v["hbm_bytes_per_launch_corrected"]
+    return None
+
+
 def cpu_baseline(n_sample, sd):
     """The reference algorithm restated on the CPU (oracle/, kind='port'), timed on this host's cores on a
     bounded sample: n_sample central slices of the same phantom, batch 1 (what the reference's --cpu forces)."""
@@ -67,7 +82,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--slices", type=int, default=300, help="slices per GPU")
     ap.add_argument("--batch", type=int, default=20)
-    ap.add_argument("--cpu-sample", type=int, default=8)
+    ap.add_argument("--cpu-sample", type=int, default=96)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -160,7 +175,9 @@ def main():
                 "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                "traffic": None,
+                "traffic": pmc_traffic("conv_igemm_f32<9"),
+                "traffic_unit": "bytes/launch (rocprofv3 PMC, separate FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected; profiles/*_pmc.json)",
+                "algorithmic_bytes_per_launch": conv["bytes"] / conv["launches"],
                 "launches": conv["launches"],
                 "avg_launch_ms": round(conv["total_ms"] / conv["launches"], 4),
                 "algorithmic_flop_per_launch": conv["flops"] / conv["launches"],
