@@ -315,16 +315,17 @@ class Engine:
         return out
 
     # -- profiling
-    def profile(self, on: bool):
+    def profile(self, on):
+        """on: False/True, or 2 for one entry per conv layer shape."""
         self.L.check(self.L.lib.lm_profile_enable(self.h, int(on)))
 
     def profile_reset(self):
         self.L.check(self.L.lib.lm_profile_reset(self.h))
 
     def profile_read(self):
-        buf = (KernelStat * 32)()
-        n = self.L.check(self.L.lib.lm_profile_read(self.h, buf, 32))
+        buf = (KernelStat * 96)()
+        n = self.L.check(self.L.lib.lm_profile_read(self.h, buf, 96))
         return [
             dict(name=buf[i].name.decode(), launches=buf[i].launches, total_ms=buf[i].total_ms, flops=buf[i].flops, bytes=buf[i].bytes)
-            for i in range(min(n, 32))
+            for i in range(min(n, 96))
         ]

@@ -221,6 +221,7 @@ int lm_apply_host(lm_engine* e, int slot, int fill_slot, const void* vol_host, i
 int lm_profile_enable(lm_engine* e, int on) {
     if (!e) return LM_ERR_INVALID;
     e->prof.on = on != 0;
+    e->prof.per_layer = on == 2;
     return LM_OK;
 }
 int lm_profile_reset(lm_engine* e) {

@@ -59,6 +59,7 @@ struct Model {
 // Per-launch HIP-event timing on the engine stream (feeds bench.py's roofline block).
 struct Profiler {
     bool on = false;
+    bool per_layer = false;  // lm_profile_enable(e, 2): one entry per conv shape instead of per kernel
     struct Rec {
         int kind;
         hipEvent_t a, b;

@@ -247,7 +247,13 @@ struct Fwd {
         const double px = (double)B * H * W;
         const double flops = 2.0 * px * L.cout * L.cin * L.taps;
         const double bytes = 4.0 * (px * (L.cin + L.cout) + (pool ? px / 4 * L.cout : 0) + (double)L.taps * L.cin * L.cout);
-        e->prof.begin(e->stream, L.taps == 9 ? kc3 : kc1, flops, bytes);
+        int kind = L.taps == 9 ? kc3 : kc1;
+        if (e->prof.on && e->prof.per_layer) {
+            char nm[48];
+            snprintf(nm, sizeof nm, "%s/H%d_Ci%d_Co%d", L.taps == 9 ? "conv3x3_igemm_f32" : "conv1x1_igemm_f32", H, L.cin, L.cout);
+            kind = e->prof.kind_id(nm);
+        }
+        e->prof.begin(e->stream, kind, flops, bytes);
         hipError_t err = (L.taps == 9) ? launch_conv3x3(p, e->stream) : launch_conv1x1(p, e->stream);
         e->prof.end(e->stream);
         if (err != hipSuccess) {

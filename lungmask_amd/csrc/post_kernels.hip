@@ -41,11 +41,32 @@ __device__ __forceinline__ void unite(int* P, int a, int b) {
     }
 }
 
-__global__ __launch_bounds__(TPB) void ccl_init_kernel(const uint8_t* __restrict__ lab, int* __restrict__ P, size_t nvox) {
-    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x)
-        P[v] = lab[v] ? (int)v : -1;
+// Initial labelling: every voxel points at the first voxel of its x-run inside its 64-voxel segment
+// (one coalesced pass, no atomics): row-runs are connected before the first union.
+__global__ __launch_bounds__(TPB) void ccl_init_runs_kernel(const uint8_t* __restrict__ lab, int* __restrict__ P, Dims d) {
+    const size_t nvox = d.nvox();
+    const size_t nseg = (nvox + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t seg = wave; seg < nseg; seg += nwaves) {
+        const size_t v = seg * 64 + lane;
+        const int L = v < nvox ? (int)lab[v] : 0;
+        const int prevL = __shfl_up(L, 1);
+        const bool same = lane > 0 && L != 0 && prevL == L && (v % d.W) != 0;
+        const unsigned long long heads = __ballot(!same);
+        const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+        const int start = 63 - __clzll((long long)(heads & upto));
+        if (v < nvox) P[v] = L ? (int)(seg * 64 + start) : -1;
+    }
 }
 
+// Hook the row-runs together.  Only unions that are not already implied are issued:
+//  * the x-neighbour only across a 64-voxel segment boundary (runs are pre-connected inside a segment);
+//  * for each earlier row (y-1 in this slice; y-1, y, y+1 in the previous slice): the voxel straight
+//    across unless the left neighbours of both are in the same runs (then the pair one step to the left
+//    implies it); the diagonal ones only when the straight one differs and this voxel's own left/right
+//    neighbour does not already carry the connection.
 template <bool C26>
 __global__ __launch_bounds__(TPB) void ccl_merge_kernel(const uint8_t* __restrict__ lab, int* P, Dims d) {
     const size_t nvox = d.nvox();
@@ -54,33 +75,23 @@ __global__ __launch_bounds__(TPB) void ccl_merge_kernel(const uint8_t* __restric
         const uint8_t L = lab[v];
         if (!L) continue;
         const int x = (int)(v % d.W), y = (int)((v / d.W) % d.H), z = (int)(v / HW);
-        if (x > 0 && lab[v - 1] == L) unite(P, (int)v, (int)(v - 1));
-        if (y > 0) {
-            const size_t u = v - d.W;
-            if (lab[u] == L) unite(P, (int)v, (int)u);
-            if (C26) {
-                if (x > 0 && lab[u - 1] == L) unite(P, (int)v, (int)(u - 1));
-                if (x + 1 < d.W && lab[u + 1] == L) unite(P, (int)v, (int)(u + 1));
+        const bool left_same = x > 0 && lab[v - 1] == L;
+        const bool right_same = x + 1 < d.W && lab[v + 1] == L;
+        if (left_same && (v & 63) == 0) unite(P, (int)v, (int)(v - 1));
+        auto row = [&](size_t u) {  // u = index of the voxel straight across in an earlier row
+            if (lab[u] == L) {
+                if (!(left_same && lab[u - 1] == L)) unite(P, (int)v, (int)u);
+            } else if (C26) {
+                if (x > 0 && !left_same && lab[u - 1] == L) unite(P, (int)v, (int)(u - 1));
+                if (x + 1 < d.W && !right_same && lab[u + 1] == L) unite(P, (int)v, (int)(u + 1));
             }
-        }
+        };
+        if (y > 0) row(v - d.W);
         if (z > 0) {
-            const size_t c = v - HW;
-            if (lab[c] == L) unite(P, (int)v, (int)c);
+            row(v - HW);
             if (C26) {
-                if (x > 0 && lab[c - 1] == L) unite(P, (int)v, (int)(c - 1));
-                if (x + 1 < d.W && lab[c + 1] == L) unite(P, (int)v, (int)(c + 1));
-                if (y > 0) {
-                    const size_t u = c - d.W;
-                    if (lab[u] == L) unite(P, (int)v, (int)u);
-                    if (x > 0 && lab[u - 1] == L) unite(P, (int)v, (int)(u - 1));
-                    if (x + 1 < d.W && lab[u + 1] == L) unite(P, (int)v, (int)(u + 1));
-                }
-                if (y + 1 < d.H) {
-                    const size_t u = c + d.W;
-                    if (lab[u] == L) unite(P, (int)v, (int)u);
-                    if (x > 0 && lab[u - 1] == L) unite(P, (int)v, (int)(u - 1));
-                    if (x + 1 < d.W && lab[u + 1] == L) unite(P, (int)v, (int)(u + 1));
-                }
+                if (y > 0) row(v - HW - d.W);
+                if (y + 1 < d.H) row(v - HW + d.W);
             }
         }
     }
@@ -168,24 +179,30 @@ __global__ __launch_bounds__(TPB) void relabel_kernel(const int* __restrict__ P,
 }
 
 // ---- per-region statistics ----------------------------------------------------------------------
+// Wave-coalesced histogram of runs: lane = voxel; the first lane of every run of equal keys adds the run length.
+__device__ __forceinline__ void wave_run_add(int key, bool counted, int* table) {
+    const int lane = threadIdx.x & 63;
+    const int prev = __shfl_up(key, 1);
+    const bool head = lane == 0 || prev != key;
+    const unsigned long long heads = __ballot(head);
+    if (head && counted) {
+        const unsigned long long higher = lane == 63 ? 0ull : (heads >> (lane + 1));
+        const int len = higher ? __ffsll((long long)higher) : 64 - lane;
+        atomicAdd(&table[key], len);
+    }
+}
+
 __global__ __launch_bounds__(TPB) void region_stats_kernel(const int* __restrict__ ids, const uint8_t* __restrict__ lab, int* area,
                                                            uint8_t* labval, size_t nvox) {
-    const size_t nchunks = (nvox + ITEMS - 1) / ITEMS;
-    for (size_t ch = (size_t)blockIdx.x * blockDim.x + threadIdx.x; ch < nchunks; ch += (size_t)gridDim.x * blockDim.x) {
-        const size_t base = ch * ITEMS;
-        int cur = 0, cnt = 0;
-        for (int i = 0; i < ITEMS; ++i) {
-            const size_t v = base + i;
-            const int id = v < nvox ? ids[v] : 0;
-            if (id != cur) {
-                if (cur) atomicAdd(&area[cur], cnt);
-                cur = id;
-                cnt = 0;
-                if (id) labval[id] = lab[v];
-            }
-            ++cnt;
-        }
-        if (cur) atomicAdd(&area[cur], cnt);
+    const size_t nseg = (nvox + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t seg = wave; seg < nseg; seg += nwaves) {
+        const size_t v = seg * 64 + lane;
+        const int id = v < nvox ? ids[v] : 0;
+        if (id && (lane == 0 || ids[v - 1] != id)) labval[id] = lab[v];
+        wave_run_add(id, id != 0, area);
     }
 }
 
@@ -228,21 +245,14 @@ __global__ __launch_bounds__(TPB) void apply_lut_kernel(const int* __restrict__ 
 
 // ---- largest component per label ----------------------------------------------------------------
 __global__ __launch_bounds__(TPB) void area_by_root_kernel(const int* __restrict__ P, int* area_by_root, size_t nvox) {
-    const size_t nchunks = (nvox + ITEMS - 1) / ITEMS;
-    for (size_t ch = (size_t)blockIdx.x * blockDim.x + threadIdx.x; ch < nchunks; ch += (size_t)gridDim.x * blockDim.x) {
-        const size_t base = ch * ITEMS;
-        int cur = -1, cnt = 0;
-        for (int i = 0; i < ITEMS; ++i) {
-            const size_t v = base + i;
-            const int r = v < nvox ? P[v] : -1;
-            if (r != cur) {
-                if (cur >= 0) atomicAdd(&area_by_root[cur], cnt);
-                cur = r;
-                cnt = 0;
-            }
-            ++cnt;
-        }
-        if (cur >= 0) atomicAdd(&area_by_root[cur], cnt);
+    const size_t nseg = (nvox + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t seg = wave; seg < nseg; seg += nwaves) {
+        const size_t v = seg * 64 + lane;
+        const int r = v < nvox ? P[v] : -1;
+        wave_run_add(r, r >= 0, area_by_root);
     }
 }
 
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(TPB) void fuse_kernel(uint8_t* res_l, const uint8_t
 hipError_t ccl_label(const uint8_t* lab, int* parent, Dims d, bool conn26, hipStream_t s) {
     const size_t n = d.nvox();
     if (n == 0) return hipSuccess;
-    LM_LAUNCH(ccl_init_kernel, dim3(grid_for(n)), dim3(TPB), 0, s, lab, parent, n);
+    LM_LAUNCH(ccl_init_runs_kernel, dim3(grid_for(n)), dim3(TPB), 0, s, lab, parent, d);
     if (conn26)
         LM_LAUNCH((ccl_merge_kernel<true>), dim3(grid_for(n)), dim3(TPB), 0, s, lab, parent, d);
     else
@@ -332,7 +342,7 @@ hipError_t ccl_rank(const int* parent, int* rank, int* ids, int* blockcnt, int* 
 }
 
 hipError_t region_stats(const int* ids, const uint8_t* lab, int* area, uint8_t* labval, size_t nvox, hipStream_t s) {
-    LM_LAUNCH(region_stats_kernel, dim3(grid_for((nvox + ITEMS - 1) / ITEMS)), dim3(TPB), 0, s, ids, lab, area, labval, nvox);
+    LM_LAUNCH(region_stats_kernel, dim3(grid_for(nvox)), dim3(TPB), 0, s, ids, lab, area, labval, nvox);
     return hipGetLastError();
 }
 
@@ -351,7 +361,7 @@ hipError_t component_max(const int* parent, const uint8_t* lab, int* area_by_roo
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(best, 0, 256 * sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
-    LM_LAUNCH(area_by_root_kernel, dim3(grid_for((nvox + ITEMS - 1) / ITEMS)), dim3(TPB), 0, s, parent, area_by_root, nvox);
+    LM_LAUNCH(area_by_root_kernel, dim3(grid_for(nvox)), dim3(TPB), 0, s, parent, area_by_root, nvox);
     LM_LAUNCH(label_max_kernel, dim3(grid_for(nvox)), dim3(TPB), 0, s, parent, lab, (const int*)area_by_root, best, nvox);
     return hipGetLastError();
 }
@@ -371,7 +381,7 @@ hipError_t flag_face_components(const int* bgparent, int* flags, Dims d, hipStre
 hipError_t flag_large_components(const int* bgparent, int* flags, int threshold, size_t nvox, hipStream_t s) {
     hipError_t e = hipMemsetAsync(flags, 0, nvox * sizeof(int), s);
     if (e != hipSuccess) return e;
-    LM_LAUNCH(area_by_root_kernel, dim3(grid_for((nvox + ITEMS - 1) / ITEMS)), dim3(TPB), 0, s, bgparent, flags, nvox);
+    LM_LAUNCH(area_by_root_kernel, dim3(grid_for(nvox)), dim3(TPB), 0, s, bgparent, flags, nvox);
     LM_LAUNCH(threshold_roots_kernel, dim3(grid_for(nvox)), dim3(TPB), 0, s, bgparent, flags, threshold, nvox);
     return hipGetLastError();
 }

@@ -20,7 +20,7 @@ for _ in range(iters):
 eng.sync()
 dt = (time.time() - t) / iters
 print(f"B={B}: {dt*1e3:.2f} ms/batch  {B/dt:.1f} slices/s  {B*96.2e9/dt/1e12:.1f} TFLOP/s")
-eng.profile(True); eng.profile_reset()
+eng.profile(2); eng.profile_reset()
 for _ in range(iters):
     eng.forward_dev(0, x, lab)
 eng.sync()
