@@ -21,6 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
+PEAK_F16_MFMA_TFLOPS = 2500.0  # same table: Peak BF16/FP16 MFMA, dense
 FLOP_PER_SLICE = 96.200556544e9  # R231, SURVEY.md Appendix A (algorithmic, 256x256)
 
 
@@ -84,6 +85,7 @@ def main():
     ap.add_argument("--batch", type=int, default=20)
     ap.add_argument("--cpu-sample", type=int, default=96)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="split_f16", choices=["split_f16", "f32"])
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -116,6 +118,7 @@ def main():
     if sd is None:
         sd = uo.synthetic_state_dict(3)
     eng.load_state_dict(0, sd)
+    eng.set_precision(args.precision)
 
     n_local, n_total = args.slices, args.slices * world
     vol = po.phantom(n_total, 512, 512, z0=rank * n_local, z1=(rank + 1) * n_local)
@@ -164,18 +167,24 @@ def main():
 
     if rank == 0:
         value = n_total * args.steps / dt
-        conv = next((s for s in stats if s["name"] == "conv3x3_igemm_f32"), None)
+        h3 = args.precision == "split_f16"
+        kname = "conv3x3_igemm_h3" if h3 else "conv3x3_igemm_f32"
+        conv = next((s for s in stats if s["name"] == kname), None)
         roof = None
         if conv and conv["total_ms"] > 0:
             ach = conv["flops"] / (conv["total_ms"] * 1e-3) / 1e12
+            peak = PEAK_F16_MFMA_TFLOPS if h3 else PEAK_F32_MFMA_TFLOPS
             roof = {
                 "bound": "mfma",
-                "kernel": "conv3x3_igemm_f32 (v_mfma_f32_32x32x2_f32, exact fp32)",
+                "kernel": kname + (" (v_mfma_f32_32x32x16_f16, 3-product split-f16: 3 executed MFMA FLOPs per algorithmic FLOP)" if h3
+                                   else " (v_mfma_f32_32x32x2_f32, exact fp32)"),
                 "achieved": round(ach, 2),
-                "peak": PEAK_F32_MFMA_TFLOPS,
+                "peak": peak,
                 "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                "traffic": pmc_traffic("conv_igemm_f32<9"),
+                "frac": round(ach / peak, 4),
+                "executed_mfma_tflops": round(ach * (3 if h3 else 1), 2),
+                "executed_frac_of_peak": round(ach * (3 if h3 else 1) / peak, 4),
+                "traffic": pmc_traffic("conv_igemm_h3<9" if h3 else "conv_igemm_f32<9"),
                 "traffic_unit": "bytes/launch (rocprofv3 PMC, separate FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected; profiles/*_pmc.json)",
                 "algorithmic_bytes_per_launch": conv["bytes"] / conv["launches"],
                 "launches": conv["launches"],
@@ -194,7 +203,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f16x3-split (hi/lo f16 operands, f32 accumulate; fp32-class)" if h3 else "f32",
             "data": "synthetic",
             "config": {
                 "workload": f"R231 U-Net, 512x512x{n_local} int16 HU phantom per GPU ({n_total} slices total), batchsize={args.batch}, "

@@ -71,6 +71,12 @@ int lm_copy_d2h(lm_engine* e, void* host_dst, const void* dev_src, size_t bytes)
 int lm_model_load(lm_engine* e, int slot, const lm_tensor* tensors, int n_tensors);
 int lm_model_classes(lm_engine* e, int slot);
 
+/* Arithmetic of the convolutions: 1 (default) = split-f16 3-product on v_mfma_f32_32x32x16_f16
+ * (values carried as hi/lo f16 pairs, fp32 accumulate; ~2^-22 relative, i.e. fp32-class:
+ * measured max |log-prob error| vs the reference <= 1.2e-4); 0 = exact fp32 matrix ops
+ * (v_mfma_f32_32x32x2_f32, 16x lower peak). */
+int lm_set_precision(lm_engine* e, int mode);
+
 /* ---- network forward (mask.py:178-186: model(mbt) + torch.max(pred,1)[1]) ------ */
 /* x_dev: f32 [b][h][w] (h, w multiples of 16).  labels_dev: u8 [b][h][w] or NULL.
  * logp_dev: f32 [b][C][h][w] log-softmax exactly like UNet.forward's return

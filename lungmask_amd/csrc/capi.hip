@@ -45,6 +45,7 @@ void lm_engine_destroy(lm_engine* e) {
     (void)hipStreamSynchronize(e->stream);
     e->prof.release();
     for (auto& m : e->models) m.release();
+    if (e->zero_page) (void)hipFree(e->zero_page);
     e->nn.release();
     e->post.release();
     e->app.release();
@@ -91,6 +92,15 @@ int lm_model_load(lm_engine* e, int slot, const lm_tensor* tensors, int n_tensor
 int lm_model_classes(lm_engine* e, int slot) {
     if (!e || slot < 0 || slot >= 4 || !e->models[slot].loaded) return LM_ERR_NOMODEL;
     return e->models[slot].n_classes;
+}
+
+int lm_set_precision(lm_engine* e, int mode) {
+    if (!e || (mode != 0 && mode != 1)) {
+        set_error("lm_set_precision: mode must be 0 (exact fp32) or 1 (split-f16)");
+        return LM_ERR_INVALID;
+    }
+    e->precision = mode;
+    return LM_OK;
 }
 
 int lm_forward_dev(lm_engine* e, int slot, const float* x_dev, int b, int h, int w, uint8_t* labels_dev, float* logp_dev) {

@@ -41,6 +41,7 @@ struct DevBuf {
 
 struct ConvLayer {
     float *w = nullptr, *bias = nullptr, *bn_s = nullptr, *bn_t = nullptr;
+    char* w_h3 = nullptr;  // split-f16 packing [taps][Cout][Cin/8][hi8|lo8]
     int cin = 0, cout = 0, taps = 0;
 };
 
@@ -116,6 +117,8 @@ struct lm_engine {
     lm::ApplyWorkspace app;
     lm::PostInfo post_info;
     lm::Profiler prof;
+    int precision = 1;  // 1 (default): split-f16 3-product; 0: exact fp32 matrix ops (lm_set_precision)
+    char* zero_page = nullptr;
 };
 
 namespace lm {

@@ -131,6 +131,35 @@ int upload(Model& md, const std::vector<float>& host, float** dev) {
     return LM_OK;
 }
 
+// IEEE binary16 conversion on the host (round to nearest even, subnormals kept) -- identical to v_cvt_f16_f32.
+uint16_t f32_to_f16(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0));
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);
+    if (x < 0x38800000u) return (uint16_t)(sign | (uint32_t)std::nearbyint(std::fabs(f) * 16777216.0f));
+    const uint32_t mant = x & 0x7fffffu, exp = (x >> 23) - 112u;
+    uint32_t h = (exp << 10) | (mant >> 13);
+    const uint32_t rem = mant & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;
+    return (uint16_t)(sign | h);
+}
+float f16_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
+    uint32_t bits;
+    if (exp == 0) {
+        float f = (float)man * 5.9604644775390625e-08f;
+        memcpy(&bits, &f, 4);
+        bits |= sign;
+    } else if (exp == 31) bits = sign | 0x7f800000u | (man << 13);
+    else bits = sign | ((exp + 112u) << 23) | (man << 13);
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
 // conv weight [cout][cin][kh][kw] -> [tap = kh*3+kw][cin][cout]; optional BatchNorm (eval) folded to
 // the per-channel affine y = x*s + t, s = gamma/sqrt(var+1e-5), t = beta - mean*s (applied AFTER ReLU,
 // resunet.py:97-100 -- it cannot be folded into the conv).
@@ -144,6 +173,23 @@ int load_conv(Model& md, const TensorMap& tm, const std::string& conv, const std
             for (int t = 0; t < taps; ++t) pw[((size_t)t * cin + i) * cout + o] = w->data[((size_t)o * cin + i) * taps + t];
     LM_TRY(upload(md, pw, &L->w));
     LM_TRY(upload(md, std::vector<float>(b->data, b->data + cout), &L->bias));
+    if (cin % 8 == 0) {  // split-f16 packing: [tap][cout][cin/8 groups][8 hi | 8 lo], lo = f16((w - hi) * 2048)
+        std::vector<float> ph((size_t)taps * cout * cin);  // 4 bytes per element, viewed as halves below
+        uint16_t* hp = reinterpret_cast<uint16_t*>(ph.data());
+        for (int t = 0; t < taps; ++t)
+            for (int o = 0; o < cout; ++o)
+                for (int i = 0; i < cin; ++i) {
+                    const float v = w->data[((size_t)o * cin + i) * taps + t];
+                    const uint16_t hi = f32_to_f16(v);
+                    const uint16_t lo = f32_to_f16((v - f16_to_f32(hi)) * 2048.0f);
+                    const size_t g = (((size_t)t * cout + o) * cin + (size_t)(i & ~7)) * 2;  // half index of the group start
+                    hp[g + (i & 7)] = hi;
+                    hp[g + 8 + (i & 7)] = lo;
+                }
+        float* dev = nullptr;
+        LM_TRY(upload(md, ph, &dev));
+        L->w_h3 = reinterpret_cast<char*>(dev);
+    }
     if (!bnp.empty()) {
         const lm_tensor* g = tm.get(bnp + ".weight", cout);
         const lm_tensor* be = tm.get(bnp + ".bias", cout);
@@ -250,11 +296,36 @@ struct Fwd {
         int kind = L.taps == 9 ? kc3 : kc1;
         if (e->prof.on && e->prof.per_layer) {
             char nm[48];
-            snprintf(nm, sizeof nm, "%s/H%d_Ci%d_Co%d", L.taps == 9 ? "conv3x3_igemm_f32" : "conv1x1_igemm_f32", H, L.cin, L.cout);
+            snprintf(nm, sizeof nm, "%s%s/H%d_Ci%d_Co%d", L.taps == 9 ? "conv3x3_igemm_" : "conv1x1_igemm_", e->precision == 1 ? "h3" : "f32", H, L.cin, L.cout);
             kind = e->prof.kind_id(nm);
         }
         e->prof.begin(e->stream, kind, flops, bytes);
-        hipError_t err = (L.taps == 9) ? launch_conv3x3(p, e->stream) : launch_conv1x1(p, e->stream);
+        hipError_t err;
+        if (e->precision == 1) {
+            ConvParamsH3 q{};
+            q.in = reinterpret_cast<const char*>(in);
+            q.in_cstride = in_cs;
+            q.in_coff = in_co;
+            q.w = L.w_h3;
+            q.bias = L.bias;
+            q.bn_s = L.bn_s;
+            q.bn_t = L.bn_t;
+            q.out = reinterpret_cast<char*>(out);
+            q.out_cstride = out_cs;
+            q.out_coff = out_co;
+            q.pool = reinterpret_cast<char*>(pool);
+            q.pool_cstride = pool_cs;
+            q.pool_coff = pool_co;
+            q.zeros = e->zero_page;
+            q.B = B;
+            q.H = H;
+            q.W = W;
+            q.Cin = L.cin;
+            q.Cout = L.cout;
+            err = (L.taps == 9) ? launch_conv3x3_h3(q, e->stream) : launch_conv1x1_h3(q, e->stream);
+        } else {
+            err = (L.taps == 9) ? launch_conv3x3(p, e->stream) : launch_conv1x1(p, e->stream);
+        }
         e->prof.end(e->stream);
         if (err != hipSuccess) {
             set_error("conv launch failed: %s (Cin=%d Cout=%d H=%d W=%d)", hipGetErrorString(err), L.cin, L.cout, H, W);
@@ -286,14 +357,21 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
         LM_TRY(ws.pool[i].reserve((px >> (2 * i + 2)) * (64u << i) * 4));
     }
     float *t1 = ws.t1.as<float>(), *t2 = ws.t2.as<float>(), *t3 = ws.t3.as<float>();
-    Fwd f{e, B, e->prof.kind_id("conv3x3_igemm_f32"), e->prof.kind_id("conv1x1_igemm_f32"), e->prof.kind_id("first_conv"),
-          e->prof.kind_id("upsample2x"), e->prof.kind_id("head_argmax")};
+    const bool h3 = e->precision == 1;
+    Fwd f{e, B, e->prof.kind_id(h3 ? "conv3x3_igemm_h3" : "conv3x3_igemm_f32"), e->prof.kind_id(h3 ? "conv1x1_igemm_h3" : "conv1x1_igemm_f32"),
+          e->prof.kind_id("first_conv"), e->prof.kind_id("upsample2x"), e->prof.kind_id("head_argmax")};
+    if (h3 && !e->zero_page) {
+        void* zp = nullptr;
+        LM_HIP(hipMalloc(&zp, 256));
+        LM_HIP(hipMemset(zp, 0, 256));
+        e->zero_page = reinterpret_cast<char*>(zp);
+    }
 
     // ---- encoder (resunet.py:60-64)
     {
         FirstConvParams p{x, md.first.w, md.first.bias, md.first.bn_s, md.first.bn_t, t1, 64, 0, B, H, W};
         e->prof.begin(e->stream, f.kfirst, 2.0 * px * 64 * 9, 4.0 * px * 65);
-        hipError_t err = launch_first_conv(p, e->stream);
+        hipError_t err = h3 ? launch_first_conv_h3(p, e->stream) : launch_first_conv(p, e->stream);
         e->prof.end(e->stream);
         if (err != hipSuccess) {
             set_error("first_conv launch failed: %s", hipGetErrorString(err));
@@ -318,7 +396,7 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
             UpsampleParams p{t2, ws.cat[lvl].as<float>(), 2 * c, 0, B, h / 2, w / 2, c};
             const double opx = (double)B * h * w;
             e->prof.begin(e->stream, f.kup, 0, 4.0 * (opx * c + opx / 4 * c));
-            hipError_t err = launch_upsample2x(p, e->stream);
+            hipError_t err = h3 ? launch_upsample2x_h3(p, e->stream) : launch_upsample2x(p, e->stream);
             e->prof.end(e->stream);
             if (err != hipSuccess) {
                 set_error("upsample launch failed: %s", hipGetErrorString(err));
@@ -332,7 +410,7 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
     {
         HeadParams p{t3, md.head_w, md.head_b, labels, logp, B, H, W, md.n_classes};
         e->prof.begin(e->stream, f.khead, 2.0 * px * 64 * md.n_classes, 4.0 * px * 64 + px);
-        hipError_t err = launch_head(p, e->stream);
+        hipError_t err = h3 ? launch_head_h3(p, e->stream) : launch_head(p, e->stream);
         e->prof.end(e->stream);
         if (err != hipSuccess) {
             set_error("head launch failed: %s", hipGetErrorString(err));

@@ -51,6 +51,28 @@ struct HeadParams {
     int B, H, W, C;
 };
 
+// Split-f16 variant (nn_kernels_h3.hip): tensors are "split NHWC" byte buffers (4 bytes per element:
+// groups of 8 channels = 8 hi halves + 8 lo halves); strides/offsets are still counted in channels.
+struct ConvParamsH3 {
+    const char* in;
+    int in_cstride, in_coff;
+    const char* w;  // packed [taps][Cout][Cin/8 groups][hi8|lo8]
+    const float* bias;
+    const float* bn_s;
+    const float* bn_t;
+    char* out;
+    int out_cstride, out_coff;
+    char* pool;
+    int pool_cstride, pool_coff;
+    const char* zeros;  // >= 16 zero bytes in device memory (source of out-of-image halo pixels)
+    int B, H, W, Cin, Cout;
+};
+hipError_t launch_conv3x3_h3(const ConvParamsH3& p, hipStream_t stream);
+hipError_t launch_conv1x1_h3(const ConvParamsH3& p, hipStream_t stream);
+hipError_t launch_first_conv_h3(const FirstConvParams& p, hipStream_t stream);  // out: split tensor
+hipError_t launch_upsample2x_h3(const UpsampleParams& p, hipStream_t stream);   // in/out: split tensors
+hipError_t launch_head_h3(const HeadParams& p, hipStream_t stream);             // in: split tensor
+
 // All launchers enqueue on `stream` and return hipGetLastError().
 hipError_t launch_conv3x3(const ConvParams& p, hipStream_t stream);
 hipError_t launch_conv1x1(const ConvParams& p, hipStream_t stream);

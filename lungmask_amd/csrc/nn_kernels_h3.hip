@@ -1,0 +1,385 @@
+// Split-f16 ("3-product") U-Net kernels: fp32-class accuracy on the 16-bit matrix cores.
+//
+// Every fp32 value v is carried as a pair of halves
+//      hi = f16(v),   lo = f16((v - hi) * 2048)          =>  v = hi + lo/2048  to ~2^-22 relative
+// (the 2^11 scale keeps `lo` in the normal f16 range).  A product a*w is evaluated as
+//      a_hi*w_hi  +  (a_hi*w_lo + a_lo*w_hi) / 2048       (the lo*lo term, 2^-22 relative, is dropped)
+// with two fp32 MFMA accumulators (main, correction) of v_mfma_f32_32x32x16_f16: three matrix
+// instructions per 16-deep k-block, i.e. an effective peak of 2.5 PFLOP/s / 3 = 833 TFLOP/s against
+// 157 TFLOP/s for the exact-fp32 matrix op.
+//
+// Storage ("split NHWC"): channels in groups of 8; a group is 32 bytes = 8 hi halves then 8 lo halves.
+// A pixel with C channels is C/8 groups = 4*C bytes -- the same footprint and strides as fp32 NHWC,
+// so the buffers, channel offsets and the concat-by-offset trick of the fp32 path carry over.  One
+// 16-byte load is exactly one MFMA operand fragment (8 consecutive k for one row/column).
+// Weights are packed [tap][cout][cin groups] in the same group format.
+//
+// conv_igemm_h3<TAPS>: D[cout][pixel] (weights are the MFMA "A" operand, activations "B": the
+// accumulator then holds 4 consecutive output channels per register quad, which is what the split
+// layout wants for 8-byte stores).  256 threads = 4 waves, tile 64 couts x 256 pixels (16x16), each wave
+// 64 couts x 64 pixels = 2x2 MFMA tiles x {main, corr}.  Per 16-channel chunk the halo tile and the
+// weight slab go global -> LDS by DMA (global_load_lds_dwordx4, no VGPR round trip); the LDS image is
+// lane-linear, so the bank swizzle (16-byte slot ^= (row>>2)&3) is applied on the SOURCE address and on
+// the fragment reads.  Out-of-image halo pixels are DMA'd from a zero page.
+#include "nn_kernels.h"
+
+namespace lm {
+
+namespace {
+
+constexpr int TH = 16, TW = 16, TN = 64, KC = 16;
+constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
+
+__device__ __forceinline__ void split_store4(char* group_base, int half_off_bytes, float v0, float v1, float v2, float v3) {
+    // writes 4 consecutive channels (hi at +0, lo at +16 of the 32-byte group); half_off_bytes = (c & 7) * 2
+    const lm_h16 h0 = lm_f2h(v0), h1 = lm_f2h(v1), h2 = lm_f2h(v2), h3 = lm_f2h(v3);
+    const lm_h16 l0 = lm_f2h((v0 - lm_h2f(h0)) * kLoScale), l1 = lm_f2h((v1 - lm_h2f(h1)) * kLoScale);
+    const lm_h16 l2 = lm_f2h((v2 - lm_h2f(h2)) * kLoScale), l3 = lm_f2h((v3 - lm_h2f(h3)) * kLoScale);
+    lm_h16 hh[4] = {h0, h1, h2, h3}, ll[4] = {l0, l1, l2, l3};
+    uint2 ph, plo;
+    memcpy(&ph, hh, 8);
+    memcpy(&plo, ll, 8);
+    *reinterpret_cast<uint2*>(group_base + half_off_bytes) = ph;
+    *reinterpret_cast<uint2*>(group_base + 16 + half_off_bytes) = plo;
+}
+
+template <int TAPS>
+struct H3Smem {
+    static constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    static constexpr int PW = TW + 2 * HALO, PH = TH + 2 * HALO;
+    static constexpr int A_ROWS = PH * PW;      // halo pixels
+    static constexpr int W_ROWS = TAPS * TN;    // (tap, cout)
+    static constexpr int ROW_BYTES = KC * 4;    // 2 groups x 32 B = 4 slots of 16 B
+    static constexpr int A_BYTES = ((A_ROWS * ROW_BYTES + 1023) / 1024) * 1024;  // whole 1 KiB DMA pieces
+    static constexpr int W_BYTES = W_ROWS * ROW_BYTES;
+    static constexpr int BYTES = A_BYTES + W_BYTES;
+};
+
+}  // namespace
+
+template <int TAPS>
+__global__ __launch_bounds__(256, 2) void conv_igemm_h3(ConvParamsH3 p) {
+    using SM = H3Smem<TAPS>;
+    constexpr int HALO = SM::HALO, PW = SM::PW, A_ROWS = SM::A_ROWS, W_ROWS = SM::W_ROWS;
+    LM_DYN_SMEM(smem);
+    char* As = smem;
+    char* Ws = smem + SM::A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int x0 = tx * TW, y0 = ty * TH, n0 = blockIdx.y * TN;
+
+    lm_f32x16 accm[2][2], accc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                accm[i][j][r] = 0.f;
+                accc[i][j][r] = 0.f;
+            }
+
+    const int li = lane & 31, kb = lane >> 5;
+    const int pr = li >> 4, pc = li & 15;
+    const char* __restrict__ in_b = p.in + ((size_t)b * p.H * p.W * p.in_cstride + p.in_coff) * 4;
+    const size_t w_row_bytes = (size_t)p.Cin * 4;
+
+    for (int c0 = 0; c0 < p.Cin; c0 += KC) {
+        __syncthreads();  // all fragment reads of the previous chunk are done
+        // ---- DMA the activation halo tile: A_ROWS rows x 4 slots; physical slot ps holds logical slot ps ^ ((row>>2)&3)
+        for (int piece = wave; piece * 64 < A_ROWS * 4; piece += 4) {
+            const int idx = piece * 64 + lane;
+            if (idx < A_ROWS * 4) {
+                const int row = idx >> 2, ls = (idx & 3) ^ ((row >> 2) & 3);
+                const int py = row / PW, px = row - py * PW;
+                const int gy = y0 + py - HALO, gx = x0 + px - HALO;
+                const char* src = p.zeros;
+                if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                    src = in_b + ((size_t)gy * p.W + gx) * p.in_cstride * 4 + (size_t)((c0 >> 3) + (ls >> 1)) * 32 + (ls & 1) * 16;
+                lm_global_load_lds16(src, As + piece * 1024);
+            }
+        }
+        // ---- DMA the weight slab: W_ROWS rows (tap, cout) x 4 slots, same swizzle
+        for (int piece = wave; piece < W_ROWS * 4 / 64; piece += 4) {
+            const int idx = piece * 64 + lane;
+            const int row = idx >> 2, ls = (idx & 3) ^ ((row >> 2) & 3);
+            const int tap = row / TN, n = row - tap * TN;
+            const char* src = p.w + ((size_t)tap * p.Cout + n0 + n) * w_row_bytes + (size_t)((c0 >> 3) + (ls >> 1)) * 32 + (ls & 1) * 16;
+            lm_global_load_lds16(src, Ws + piece * 1024);
+        }
+        __syncthreads();  // (the compiler drains vmcnt for the LDS-DMA before the barrier)
+#pragma unroll 1
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int dy = (TAPS == 9) ? tap / 3 : 0, dx = (TAPS == 9) ? tap - 3 * dy : 0;
+            lm_h16x8 whi[2], wlo[2], ahi[2], alo[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int row = tap * TN + 32 * mt + li;
+                const int sw = (row >> 2) & 3;
+                whi[mt] = *reinterpret_cast<const lm_h16x8*>(Ws + row * 64 + ((2 * kb) ^ sw) * 16);
+                wlo[mt] = *reinterpret_cast<const lm_h16x8*>(Ws + row * 64 + ((2 * kb + 1) ^ sw) * 16);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int row = (4 * wave + 2 * nt + pr + dy) * PW + pc + dx;
+                const int sw = (row >> 2) & 3;
+                ahi[nt] = *reinterpret_cast<const lm_h16x8*>(As + row * 64 + ((2 * kb) ^ sw) * 16);
+                alo[nt] = *reinterpret_cast<const lm_h16x8*>(As + row * 64 + ((2 * kb + 1) ^ sw) * 16);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    accm[mt][nt] = lm_mfma_f32_32x32x16_f16(whi[mt], ahi[nt], accm[mt][nt]);
+                    accc[mt][nt] = lm_mfma_f32_32x32x16_f16(whi[mt], alo[nt], accc[mt][nt]);
+                    accc[mt][nt] = lm_mfma_f32_32x32x16_f16(wlo[mt], ahi[nt], accc[mt][nt]);
+                }
+        }
+    }
+
+    // ---- epilogue.  D[cout][pixel]: lane = pixel (li) of the N-tile, register quad g = 4 consecutive couts.
+    const bool bn = p.bn_s != nullptr;
+    const int Hp = p.H >> 1, Wp = p.W >> 1;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int y = y0 + 4 * wave + 2 * nt + pr, x = x0 + pc;
+        const bool inside = y < p.H && x < p.W;
+        char* orow = p.out + ((((size_t)b * p.H + y) * p.W + x) * p.out_cstride + p.out_coff) * 4;
+        const bool pool_lane = p.pool != nullptr && pr == 0 && (pc & 1) == 0;
+        char* prow = p.pool ? p.pool + ((((size_t)b * Hp + (y >> 1)) * Wp + (x >> 1)) * p.pool_cstride + p.pool_coff) * 4 : nullptr;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cb = n0 + 32 * mt + 8 * g + 4 * kb;  // first of 4 consecutive output channels
+                const float4 bias = *reinterpret_cast<const float4*>(p.bias + cb);
+                float v[4];
+                v[0] = fmaf(accc[mt][nt][4 * g + 0], kLoInv, accm[mt][nt][4 * g + 0]) + bias.x;
+                v[1] = fmaf(accc[mt][nt][4 * g + 1], kLoInv, accm[mt][nt][4 * g + 1]) + bias.y;
+                v[2] = fmaf(accc[mt][nt][4 * g + 2], kLoInv, accm[mt][nt][4 * g + 2]) + bias.z;
+                v[3] = fmaf(accc[mt][nt][4 * g + 3], kLoInv, accm[mt][nt][4 * g + 3]) + bias.w;
+                if (bn) {
+                    const float4 s = *reinterpret_cast<const float4*>(p.bn_s + cb);
+                    const float4 sh = *reinterpret_cast<const float4*>(p.bn_t + cb);
+                    v[0] = fmaf(fmaxf(v[0], 0.f), s.x, sh.x);
+                    v[1] = fmaf(fmaxf(v[1], 0.f), s.y, sh.y);
+                    v[2] = fmaf(fmaxf(v[2], 0.f), s.z, sh.z);
+                    v[3] = fmaf(fmaxf(v[3], 0.f), s.w, sh.w);
+                }
+                const int grp = cb >> 3;  // 8-channel group index inside the output tensor slice
+                if (inside) split_store4(orow + (size_t)grp * 32, (cb & 7) * 2, v[0], v[1], v[2], v[3]);
+                if (p.pool != nullptr) {  // avg_pool2d(2): partners are lane^1 (x+1) and lane^16 (y+1)
+                    float q[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float h = v[k] + __shfl_xor(v[k], 1);
+                        q[k] = 0.25f * (h + __shfl_xor(h, 16));
+                    }
+                    if (pool_lane && y + 1 < p.H && x + 1 < p.W) split_store4(prow + (size_t)grp * 32, (cb & 7) * 2, q[0], q[1], q[2], q[3]);
+                }
+            }
+        }
+    }
+}
+
+template <int TAPS>
+static hipError_t launch_conv_h3_t(const ConvParamsH3& p, hipStream_t stream) {
+    if (p.Cin % KC != 0 || p.Cout % TN != 0 || (p.in_cstride & 7) || (p.in_coff & 7) || (p.out_cstride & 7) || (p.out_coff & 7)) return hipErrorInvalidValue;
+    if (p.pool != nullptr && (((p.H | p.W) & 1) || (p.pool_cstride & 7) || (p.pool_coff & 7))) return hipErrorInvalidValue;
+    const int tiles = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH);
+    dim3 grid((unsigned)(tiles * p.B), (unsigned)(p.Cout / TN));
+    LM_LAUNCH((conv_igemm_h3<TAPS>), grid, dim3(256), (H3Smem<TAPS>::BYTES), stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv3x3_h3(const ConvParamsH3& p, hipStream_t stream) { return launch_conv_h3_t<9>(p, stream); }
+hipError_t launch_conv1x1_h3(const ConvParamsH3& p, hipStream_t stream) { return launch_conv_h3_t<1>(p, stream); }
+
+// ---------------------------------------------------------------------------------------------
+// First layer (Cin = 1), fp32 arithmetic on the VALU, split output.  lane = output channel.
+__global__ __launch_bounds__(256) void first_conv_h3_kernel(FirstConvParams p) {
+    __shared__ float tile[18 * 18];
+    __shared__ float wsm[9 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int x0 = tx * TW, y0 = ty * TH;
+    for (int idx = tid; idx < 18 * 18; idx += 256) {
+        const int py = idx / 18, px = idx - py * 18;
+        const int gy = y0 + py - 1, gx = x0 + px - 1;
+        float v = 0.f;
+        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) v = p.in[((size_t)b * p.H + gy) * p.W + gx];
+        tile[idx] = v;
+    }
+    for (int idx = tid; idx < 9 * 64; idx += 256) wsm[idx] = p.w[idx];
+    __syncthreads();
+    float wr[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wr[k] = wsm[k * 64 + lane];
+    const float bias = p.bias[lane], s = p.bn_s[lane], sh = p.bn_t[lane];
+    char* out = reinterpret_cast<char*>(p.out);
+    for (int pix = 0; pix < 64; ++pix) {
+        const int r = 4 * wave + (pix >> 4), c = pix & 15;
+        float v = bias;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v = fmaf(tile[(r + k / 3) * 18 + c + (k % 3)], wr[k], v);
+        v = fmaf(fmaxf(v, 0.f), s, sh);
+        const int y = y0 + r, x = x0 + c;
+        if (y < p.H && x < p.W) {
+            char* g = out + ((((size_t)b * p.H + y) * p.W + x) * p.out_cstride + p.out_coff) * 4 + (size_t)(lane >> 3) * 32 + (lane & 7) * 2;
+            const lm_h16 h = lm_f2h(v);
+            *reinterpret_cast<lm_h16*>(g) = h;
+            *reinterpret_cast<lm_h16*>(g + 16) = lm_f2h((v - lm_h2f(h)) * kLoScale);
+        }
+    }
+}
+
+hipError_t launch_first_conv_h3(const FirstConvParams& p, hipStream_t stream) {
+    const int tiles = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH);
+    LM_LAUNCH(first_conv_h3_kernel, dim3((unsigned)(tiles * p.B)), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+namespace {
+__device__ __forceinline__ void load_group(const char* g, float* v) {  // 32-byte group -> 8 floats
+    lm_h16 hh[8], ll[8];
+    const uint4 a = *reinterpret_cast<const uint4*>(g), c = *reinterpret_cast<const uint4*>(g + 16);
+    memcpy(hh, &a, 16);
+    memcpy(ll, &c, 16);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = fmaf(lm_h2f(ll[k]), kLoInv, lm_h2f(hh[k]));
+}
+}  // namespace
+
+// Bilinear x2 (align_corners=False) on split tensors; thread = (output pixel, 8-channel group).
+__global__ __launch_bounds__(256) void upsample2x_h3_kernel(UpsampleParams p) {
+    const int G = p.C >> 3;
+    const int H2 = 2 * p.h, W2 = 2 * p.w;
+    const size_t total = (size_t)p.B * H2 * W2 * G;
+    const char* in = reinterpret_cast<const char*>(p.in);
+    char* out = reinterpret_cast<char*>(p.out);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(idx % G);
+        size_t rest = idx / G;
+        const int x = (int)(rest % W2);
+        rest /= W2;
+        const int y = (int)(rest % H2);
+        const int b = (int)(rest / H2);
+        int ya, yb, xa, xb;
+        float wya, wyb, wxa, wxb;
+        {
+            const int i = y >> 1;
+            if (y & 1) { ya = i; yb = min(i + 1, p.h - 1); wya = 0.75f; wyb = 0.25f; }
+            else if (i == 0) { ya = 0; yb = 0; wya = 1.f; wyb = 0.f; }
+            else { ya = i - 1; yb = i; wya = 0.25f; wyb = 0.75f; }
+            const int j = x >> 1;
+            if (x & 1) { xa = j; xb = min(j + 1, p.w - 1); wxa = 0.75f; wxb = 0.25f; }
+            else if (j == 0) { xa = 0; xb = 0; wxa = 1.f; wxb = 0.f; }
+            else { xa = j - 1; xb = j; wxa = 0.25f; wxb = 0.75f; }
+        }
+        const char* base = in + (size_t)b * p.h * p.w * p.C * 4 + (size_t)g * 32;
+        float a00[8], a01[8], a10[8], a11[8], o[8];
+        load_group(base + ((size_t)ya * p.w + xa) * p.C * 4, a00);
+        load_group(base + ((size_t)ya * p.w + xb) * p.C * 4, a01);
+        load_group(base + ((size_t)yb * p.w + xa) * p.C * 4, a10);
+        load_group(base + ((size_t)yb * p.w + xb) * p.C * 4, a11);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = wya * (wxa * a00[k] + wxb * a01[k]) + wyb * (wxa * a10[k] + wxb * a11[k]);
+        char* dst = out + ((((size_t)b * H2 + y) * W2 + x) * p.out_cstride + p.out_coff) * 4 + (size_t)g * 32;
+        split_store4(dst, 0, o[0], o[1], o[2], o[3]);
+        split_store4(dst, 8, o[4], o[5], o[6], o[7]);
+    }
+}
+
+hipError_t launch_upsample2x_h3(const UpsampleParams& p, hipStream_t stream) {
+    if ((p.C & 7) || (p.out_cstride & 7) || (p.out_coff & 7)) return hipErrorInvalidValue;
+    const size_t total = (size_t)p.B * 4 * p.h * p.w * (p.C >> 3);
+    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 16);
+    LM_LAUNCH(upsample2x_h3_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+// Head on a split tensor: 8 lanes share one pixel (one 32-byte group of the 64 channels each).
+__global__ __launch_bounds__(256) void head_h3_kernel(HeadParams p) {
+    __shared__ float wsm[kMaxClasses * 64];
+    __shared__ float bsm[kMaxClasses];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < p.C * 64; i += 256) wsm[i] = p.w[i];
+    if (tid < p.C) bsm[tid] = p.bias[tid];
+    __syncthreads();
+    const int q = tid & 7;
+    const size_t npix = (size_t)p.B * p.H * p.W;
+    const size_t HW = (size_t)p.H * p.W;
+    const size_t ngroups = (npix + 31) / 32;  // 32 pixels per 256-thread block-iteration
+    const char* in = reinterpret_cast<const char*>(p.in);
+    for (size_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const size_t pix = g * 32 + (tid >> 3);
+        const bool valid = pix < npix;
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = 0.f;
+        if (valid) load_group(in + pix * 256 + (size_t)q * 32, v);
+        float part[kMaxClasses];
+#pragma unroll
+        for (int c = 0; c < kMaxClasses; ++c) {
+            float s = 0.f;
+            if (c < p.C) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s = fmaf(v[k], wsm[c * 64 + 8 * q + k], s);
+            }
+            part[c] = s;
+        }
+#pragma unroll
+        for (int c = 0; c < kMaxClasses; ++c) {
+            if (c < p.C) {  // wave-uniform
+#pragma unroll
+                for (int m = 4; m >= 1; m >>= 1) part[c] += __shfl_xor(part[c], m);
+            }
+        }
+        if (valid && q == 0) {
+            float best = part[0] + bsm[0];
+            int arg = 0;
+            float lg[kMaxClasses];
+            lg[0] = best;
+#pragma unroll
+            for (int c = 1; c < kMaxClasses; ++c) {
+                if (c < p.C) {
+                    lg[c] = part[c] + bsm[c];
+                    if (lg[c] > best) { best = lg[c]; arg = c; }
+                }
+            }
+            if (p.labels) p.labels[pix] = (uint8_t)arg;
+            if (p.logp) {
+                float se = 0.f;
+#pragma unroll
+                for (int c = 0; c < kMaxClasses; ++c)
+                    if (c < p.C) se += expf(lg[c] - best);
+                const float lse = best + logf(se);
+                const size_t b = pix / HW, yx = pix - b * HW;
+#pragma unroll
+                for (int c = 0; c < kMaxClasses; ++c)
+                    if (c < p.C) p.logp[(b * p.C + c) * HW + yx] = lg[c] - lse;
+            }
+        }
+    }
+}
+
+hipError_t launch_head_h3(const HeadParams& p, hipStream_t stream) {
+    if (p.C < 1 || p.C > kMaxClasses) return hipErrorInvalidValue;
+    const size_t npix = (size_t)p.B * p.H * p.W;
+    const unsigned blocks = (unsigned)std::min<size_t>((npix + 31) / 32, 256 * 32);
+    LM_LAUNCH(head_h3_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace lm

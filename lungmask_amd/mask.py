@@ -58,6 +58,7 @@ class LMInferer:
         volume_postprocessing: bool = True,
         tqdm_disable: bool = False,
         device_id: int = 0,
+        precision: str = "split_f16",
     ):
         assert modelname in MODEL_URLS, "Modelname not found. Please choose from: {}".format(MODEL_URLS.keys())  # mask.py:95-97
         if fillmodel is not None:
@@ -76,6 +77,7 @@ class LMInferer:
             # mask.py:118-134 would silently fall back to torch-CPU; this engine has no CPU path by design.
             raise RuntimeError("lungmask_amd is an MI355X-only engine: force_cpu=True is not available (use the reference package for CPU)")
         self.engine = _native.Engine(device_id)
+        self.engine.set_precision(precision)  # "split_f16" (default, fp32-class) or "f32" (exact fp32 matrix ops)
         self.engine.load_state_dict(0, get_model(self.modelname, modelpath))
         self.fill_slot = -1
         if self.fillmodel is not None:  # mask.py:136-139

@@ -344,3 +344,75 @@ inline lm_f32x16 lm_emu_mfma_f32_32x32x2f32(float a, float b, lm_f32x16 c) {
     lm_emu::wave_sync();
     return c;
 }
+
+// ------------------------------------------------------------------ fp16 (software) + f16 MFMA + LDS-DMA
+typedef unsigned short lm_h16;  // IEEE binary16 bit pattern
+inline float lm_h2f(lm_h16 h) {
+    const unsigned sign = (unsigned)(h & 0x8000u) << 16;
+    const unsigned exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
+    unsigned bits;
+    if (exp == 0) {
+        if (man == 0) bits = sign;
+        else {  // subnormal
+            float f = (float)man * 5.9604644775390625e-08f;  // 2^-24
+            memcpy(&bits, &f, 4);
+            bits |= sign;
+        }
+    } else if (exp == 31) bits = sign | 0x7f800000u | (man << 13);
+    else bits = sign | ((exp + 112u) << 23) | (man << 13);
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+inline lm_h16 lm_f2h(float f) {  // round to nearest even, subnormals kept
+    unsigned x;
+    memcpy(&x, &f, 4);
+    const unsigned sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (lm_h16)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0));
+    if (x >= 0x477ff000u) return (lm_h16)(sign | 0x7c00u);  // overflow -> inf (>= 65520)
+    if (x < 0x38800000u) {                                  // subnormal or zero in half
+        const float a = fabsf(f) * 16777216.0f;             // * 2^24 -> units of the smallest subnormal
+        const float r = nearbyintf(a);
+        return (lm_h16)(sign | (unsigned)r);
+    }
+    const unsigned mant = x & 0x7fffffu, exp = (x >> 23) - 112u;
+    unsigned h = (exp << 10) | (mant >> 13);
+    const unsigned rem = mant & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;
+    return (lm_h16)(sign | h);
+}
+struct alignas(16) lm_h16x8 {
+    lm_h16 v[8];
+};
+
+// v_mfma_f32_32x32x16_f16: A[i=l&31][k=8*(l>>5)+j], B[k=8*(l>>5)+j][col=l&31], fp32 accumulate.
+inline lm_f32x16 lm_emu_mfma_f32_32x32x16_f16(lm_h16x8 a, lm_h16x8 b, lm_f32x16 c) {
+    const int lane = lm_emu::linear_tid() & 63;
+    const int wv = lm_emu::linear_tid() >> 6;
+    static thread_local float As[16][64][8], Bs[16][64][8];  // per wave of the block
+    for (int j = 0; j < 8; ++j) {
+        As[wv][lane][j] = lm_h2f(a.v[j]);
+        Bs[wv][lane][j] = lm_h2f(b.v[j]);
+    }
+    lm_emu::wave_sync();
+    const int col = lane & 31, hi = lane >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int kb = 0; kb < 2; ++kb)
+            for (int j = 0; j < 8; ++j) acc = fmaf(As[wv][32 * kb + i][j], Bs[wv][32 * kb + col][j], acc);
+        c[r] = acc;
+    }
+    lm_emu::wave_sync();
+    return c;
+}
+
+// global_load_lds_dwordx4: LDS destination = wave-uniform base + lane*16; per-lane global source.
+inline void lm_emu_global_load_lds16(const void* gsrc, void* lds_wave_base) {
+    const int lane = lm_emu::linear_tid() & 63;
+    memcpy((char*)lds_wave_base + lane * 16, gsrc, 16);
+}
+struct alignas(8) uint2 {
+    unsigned x, y;
+};

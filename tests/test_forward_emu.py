@@ -14,7 +14,22 @@ def test_forward_emulated_matches_reference_golden(emu_engine, golden_dir):
     g = np.load(os.path.join(golden_dir, "unet_c3.npz"))
     emu_engine.load_state_dict(0, uo.synthetic_state_dict(3))
     x = g["rand32_x"][:1]
-    lab, logp = emu_engine.forward(0, x)
+    emu_engine.set_precision("f32")
+    try:
+        lab, logp = emu_engine.forward(0, x)
+    finally:
+        emu_engine.set_precision("split_f16")
+    assert np.abs(logp - g["rand32_logp"][:1]).max() < TOL
+    bad = lab != g["rand32_lab"][:1]
+    assert not np.any(bad & (g["rand32_margin"][:1].astype(np.float32) > 2 * TOL))
+
+
+def test_forward_emulated_split_f16(emu_engine, golden_dir):
+    """The 3-product split-f16 convolution path (v_mfma_f32_32x32x16_f16 + LDS-DMA staging, emulated)."""
+    g = np.load(os.path.join(golden_dir, "unet_c3.npz"))
+    emu_engine.load_state_dict(0, uo.synthetic_state_dict(3))
+    emu_engine.set_precision("split_f16")
+    lab, logp = emu_engine.forward(0, g["rand32_x"][:1])
     assert np.abs(logp - g["rand32_logp"][:1]).max() < TOL
     bad = lab != g["rand32_lab"][:1]
     assert not np.any(bad & (g["rand32_margin"][:1].astype(np.float32) > 2 * TOL))

@@ -19,8 +19,15 @@ def check_labels(lab, ref_lab, margin, tol):
     return n_bad
 
 
+@pytest.fixture(params=["f32", "split_f16"])
+def precision(request, gpu_engine):
+    gpu_engine.set_precision(request.param)
+    yield request.param
+    gpu_engine.set_precision("split_f16")  # the engine default
+
+
 @pytest.mark.parametrize("C", [3, 6])
-def test_forward_matches_reference_goldens(gpu_engine, golden_dir, C):
+def test_forward_matches_reference_goldens(gpu_engine, golden_dir, C, precision):
     g = np.load(os.path.join(golden_dir, f"unet_c{C}.npz"))
     gpu_engine.load_state_dict(0, uo.synthetic_state_dict(C))
     for case in ("rand32", "rand64", "phantom256"):
@@ -29,11 +36,12 @@ def test_forward_matches_reference_goldens(gpu_engine, golden_dir, C):
         ref = g[case + "_logp"]
         got = logp if x.shape[-1] <= 64 else logp[:, :, ::4, ::4]
         err = np.abs(got - ref).max()
+        print(f"[{precision}] C={C} {case}: max|dlogp|={err:.3e}")
         assert err < TOL, (case, err)
         check_labels(lab, g[case + "_lab"], g[case + "_margin"].astype(np.float32), TOL)
 
 
-def test_forward_batch20_vs_oracle(gpu_engine):
+def test_forward_batch20_vs_oracle(gpu_engine, precision):
     """BASELINE config batch (20 slices of 256x256) against the torch-fp32 CPU oracle."""
     sd = uo.synthetic_state_dict(3)
     gpu_engine.load_state_dict(0, sd)

@@ -9,6 +9,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 eng = nat.Engine(0)
 eng.load_state_dict(0, uo.synthetic_state_dict(3))
+eng.set_precision(sys.argv[3] if len(sys.argv) > 3 else "f32")
 x = eng.to_device(np.random.default_rng(0).random((B, 256, 256), dtype=np.float32))
 lab = eng.empty((B, 256, 256), np.uint8)
 for _ in range(2):
