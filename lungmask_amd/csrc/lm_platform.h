@@ -32,6 +32,16 @@ __device__ __forceinline__ lm_f32x16 lm_mfma_f32_32x32x16_f16(lm_h16x8 a, lm_h16
 #endif
 }
 
+// A value the program knows to be wave-uniform, made provably so for the compiler (SGPR instead of a
+// per-lane VGPR + waterfall loop).
+__device__ __forceinline__ int lm_uniform(int x) {
+#ifdef LM_EMU_BUILD
+    return x;
+#else
+    return __builtin_amdgcn_readfirstlane(x);
+#endif
+}
+
 // 16-byte global -> LDS DMA (global_load_lds_dwordx4): destination is the WAVE-UNIFORM base + lane*16.
 __device__ __forceinline__ void lm_global_load_lds16(const void* gsrc, void* lds_wave_base) {
 #ifdef LM_EMU_BUILD
@@ -52,3 +62,38 @@ __device__ __forceinline__ lm_f32x16 lm_mfma_f32_32x32x2(float a, float b, lm_f3
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 #endif
 }
+
+// 16-byte LDS reads that the compiler's waitcnt pass cannot see (so it does not drain an in-flight LDS-DMA
+// in front of them), with an explicit counted wait that names every destination register.
+#ifdef LM_EMU_BUILD
+#define LM_OPAQUE3(a, b, c) \
+    do {                    \
+    } while (0)
+#define LM_LDS_WAIT6(N, a, b, c, d, e, f) \
+    do {                                  \
+    } while (0)
+#define LM_LDS_READ128(dst, ptr, OFF) (dst) = *reinterpret_cast<const lm_h16x8*>(reinterpret_cast<const char*>(ptr) + (OFF))
+#define LM_LDS_WAIT8(N, a, b, c, d, e, f, g, h) \
+    do {                                        \
+    } while (0)
+#else
+#define LM_OPAQUE3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
+#define LM_LDS_WAIT6(N, a, b, c, d, e, f)                                                                         \
+    do {                                                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "i"(N) : "memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
+#define LM_LDS_READ128(dst, ptr, OFF)                                                                             \
+    asm volatile("ds_read_b128 %0, %1 offset:%2"                                                                  \
+                 : "=v"(dst)                                                                                      \
+                 : "v"((unsigned)(size_t)(__attribute__((address_space(3))) const char*)(ptr)), "i"(OFF)          \
+                 : "memory")
+#define LM_LDS_WAIT8(N, a, b, c, d, e, f, g, h)                                                                   \
+    do {                                                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(%8)"                                                                      \
+                     : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h)                     \
+                     : "i"(N)                                                                                     \
+                     : "memory");                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
+#endif

@@ -21,6 +21,8 @@
 // weight slab go global -> LDS by DMA (global_load_lds_dwordx4, no VGPR round trip); the LDS image is
 // lane-linear, so the bank swizzle (16-byte slot ^= (row>>2)&3) is applied on the SOURCE address and on
 // the fragment reads.  Out-of-image halo pixels are DMA'd from a zero page.
+#include <cstdlib>
+
 #include "nn_kernels.h"
 
 namespace lm {
@@ -188,10 +190,223 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(ConvParamsH3 p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wide variant for W % 32 == 0 (every level but the 16x16 bottleneck): ONE 1024-thread workgroup per CU =
+// 16 waves (4 per SIMD, <= 128 VGPRs), tile 64 couts x 512 pixels (16 rows x 32 cols).  Wave w owns the 2-row x
+// 16-col pixel patch (w>>1, w&1) = one 32-pixel N-tile against both 32-cout M-tiles: 2 x {main, corr}
+// accumulators = 64 registers.  LDS is DOUBLE BUFFERED in two separate static objects (2 x 75 KiB): the DMA
+// of chunk i+1 is issued right after the single barrier of chunk i and lands while chunk i's MFMAs run.
+// Fragment reads are hand-issued ds_read_b128 (LM_LDS_READ128): the compiler's waitcnt pass would otherwise
+// drain the in-flight LDS-DMA in front of them.  DMA source offsets are computed once per lane.
+namespace {
+template <int TAPS>
+struct H3WSmem {
+    static constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    static constexpr int TWW = 32;
+    static constexpr int PW = TWW + 2 * HALO, PH = TH + 2 * HALO;
+    static constexpr int A_ROWS = PH * PW;
+    static constexpr int W_ROWS = TAPS * TN;
+    static constexpr int A_PIECES = (A_ROWS * 4 + 63) / 64, W_PIECES = W_ROWS * 4 / 64;
+    static constexpr int A_BYTES = A_PIECES * 1024, W_BYTES = W_PIECES * 1024;
+    static constexpr int BUF_BYTES = A_BYTES + W_BYTES;
+    static constexpr int NW = 16;
+    static constexpr int A_PER_WAVE = (A_PIECES + NW - 1) / NW, W_PER_WAVE = (W_PIECES + NW - 1) / NW;
+};
+}  // namespace
+
+template <int TAPS>
+__global__ __launch_bounds__(1024) void conv_igemm_h3w(ConvParamsH3 p) {
+    using SM = H3WSmem<TAPS>;
+    constexpr int HALO = SM::HALO, PW = SM::PW, TWW = SM::TWW, NW = SM::NW;
+    // Two SEPARATE static LDS objects (see above).
+    __shared__ __attribute__((aligned(1024))) char buf0[SM::BUF_BYTES];
+    __shared__ __attribute__((aligned(1024))) char buf1[SM::BUF_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = lm_uniform(tid >> 6);
+    const int tiles_x = p.W / TWW, tiles_y = (p.H + TH - 1) / TH;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int x0 = tx * TWW, y0 = ty * TH, n0 = blockIdx.y * TN;
+
+    lm_f32x16 accm[2], accc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            accm[i][r] = 0.f;
+            accc[i][r] = 0.f;
+        }
+
+    const int li = lane & 31, kb = lane >> 5;
+    const int pr = li >> 4, pc = li & 15;
+    const int ry = 2 * (wave >> 1) + pr, rx = 16 * (wave & 1) + pc;  // this lane's pixel inside the 16x32 tile
+    const char* __restrict__ in_b = p.in + ((size_t)b * p.H * p.W * p.in_cstride + p.in_coff) * 4;
+    const char* __restrict__ w_b = p.w + (size_t)n0 * p.Cin * 4;
+
+    // per-lane DMA source offsets: 32-bit byte offsets from ONE wave-uniform base each (=> the saddr form of
+    // global_load_lds: SGPR base + one VGPR offset); kSkip = lane issues nothing.  Out-of-image halo pixels are
+    // not DMA'd at all: their LDS slots are zeroed once, in both buffers, and never written again.
+    constexpr unsigned kSkip = 0xffffffffu;
+    unsigned offA[SM::A_PER_WAVE], offW0;
+#pragma unroll
+    for (int j = 0; j < SM::A_PER_WAVE; ++j) {
+        const int piece = wave + NW * j, idx = piece * 64 + lane;
+        unsigned off = kSkip;
+        if (piece < SM::A_PIECES && idx < SM::A_ROWS * 4) {
+            const int row = idx >> 2;
+            const int py = row / PW, px = row - py * PW;
+            const int ls = (idx & 3) ^ ((px >> 2) & 3);  // swizzle by the halo COLUMN only: tap row shifts (dy) are then plain byte offsets
+            const int gy = y0 + py - HALO, gx = x0 + px - HALO;
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+                off = (unsigned)((gy * p.W + gx) * p.in_cstride * 4 + (ls >> 1) * 32 + (ls & 1) * 16);
+            } else {
+                const uint4 z = {0u, 0u, 0u, 0u};
+                *reinterpret_cast<uint4*>(buf0 + idx * 16) = z;
+                *reinterpret_cast<uint4*>(buf1 + idx * 16) = z;
+            }
+        }
+        offA[j] = off;
+    }
+    {   // weight pieces wave, wave+16, wave+32: 256 rows = 4 taps apart, same cout and slot -> one VGPR + a uniform stride
+        const int idx = wave * 64 + lane;
+        const int row = idx >> 2, ls = (idx & 3) ^ ((row >> 2) & 3);
+        const int tap = row / TN, n = row - tap * TN;
+        offW0 = (unsigned)((tap * p.Cout + n) * p.Cin * 4 + (ls >> 1) * 32 + (ls & 1) * 16);
+    }
+    const unsigned w_piece_stride = (unsigned)(NW * 64 / 4 / TN) * (unsigned)p.Cout * (unsigned)p.Cin * 4u;
+    auto issue_dma = [&](int c0, char* buf) {
+        const unsigned cb = (unsigned)c0 * 4u;
+#pragma unroll
+        for (int j = 0; j < SM::A_PER_WAVE; ++j) {
+            if (offA[j] != kSkip) lm_global_load_lds16(in_b + (size_t)(offA[j] + cb), buf + (wave + NW * j) * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < SM::W_PER_WAVE; ++j) {
+            if (wave + NW * j < SM::W_PIECES)  // wave-uniform
+                lm_global_load_lds16(w_b + (size_t)(offW0 + (unsigned)j * w_piece_stride + cb), buf + SM::A_BYTES + (wave + NW * j) * 1024);
+        }
+    };
+
+    // Fragment addresses, all loop invariant: weights = 2 bases + tap*4096 (+2048 for the second M-tile) as
+    // immediates; activations = one base per dx (the swizzle depends on the halo column rx+dx only) + dy*PW*64.
+    const int wsw = (li >> 2) & 3;  // ((tap*64 + 32*mt + li) >> 2) & 3 == (li >> 2) & 3
+    const int w_hi_off = li * 64 + ((2 * kb) ^ wsw) * 16;  // the lo fragment sits in the neighbouring slot: address ^ 16
+    int a_hi_off[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        const int px = rx + dx, sw = (px >> 2) & 3;
+        a_hi_off[dx] = (ry * PW + px) * 64 + ((2 * kb) ^ sw) * 16;
+    }
+    auto compute = [&](const char* As) {
+        const char* Ws = As + SM::A_BYTES;
+        lm_h16x8 f[6];  // whi0 whi1 wlo0 wlo1 ahi alo
+#pragma unroll
+        for (int dy = 0; dy < (TAPS == 9 ? 3 : 1); ++dy) {
+#pragma unroll
+            for (int dx = 0; dx < (TAPS == 9 ? 3 : 1); ++dx) {
+                constexpr int ROWB = PW * 64;
+                const int tap = 3 * dy + dx;
+                // dy*ROWB and tap*4096 are folded into the ds_read immediates via the three literal cases below
+                const int a_lo = a_hi_off[dx] ^ 16;
+                if (dy == 0) {
+                    LM_LDS_READ128(f[4], As + a_hi_off[dx], 0);
+                    LM_LDS_READ128(f[5], As + a_lo, 0);
+                } else if (dy == 1) {
+                    LM_LDS_READ128(f[4], As + a_hi_off[dx], ROWB);
+                    LM_LDS_READ128(f[5], As + a_lo, ROWB);
+                } else {
+                    LM_LDS_READ128(f[4], As + a_hi_off[dx], 2 * ROWB);
+                    LM_LDS_READ128(f[5], As + a_lo, 2 * ROWB);
+                }
+                const char* wh = Ws + w_hi_off + tap * (TN * 64);
+                const char* wl = Ws + (w_hi_off ^ 16) + tap * (TN * 64);
+                LM_LDS_READ128(f[0], wh, 0);
+                LM_LDS_READ128(f[1], wh, 2048);
+                LM_LDS_READ128(f[2], wl, 0);
+                LM_LDS_READ128(f[3], wl, 2048);
+                LM_LDS_WAIT6(0, f[0], f[1], f[2], f[3], f[4], f[5]);
+                accm[0] = lm_mfma_f32_32x32x16_f16(f[0], f[4], accm[0]);
+                accc[0] = lm_mfma_f32_32x32x16_f16(f[0], f[5], accc[0]);
+                accm[1] = lm_mfma_f32_32x32x16_f16(f[1], f[4], accm[1]);
+                accc[1] = lm_mfma_f32_32x32x16_f16(f[1], f[5], accc[1]);
+                accc[0] = lm_mfma_f32_32x32x16_f16(f[2], f[4], accc[0]);
+                accc[1] = lm_mfma_f32_32x32x16_f16(f[3], f[4], accc[1]);
+            }
+        }
+    };
+
+    // chunk loop, unrolled by two so that each half names its LDS object statically
+    const int nchunks = p.Cin / KC;
+    issue_dma(0, buf0);
+    for (int ci = 0; ci < nchunks; ci += 2) {
+        __syncthreads();  // chunk ci has landed in buf0 (LDS-DMA drained here); everyone is done reading buf1
+        if (ci + 1 < nchunks) issue_dma((ci + 1) * KC, buf1);
+        compute(buf0);
+        if (ci + 1 < nchunks) {
+            __syncthreads();  // chunk ci+1 has landed in buf1; everyone is done reading buf0
+            if (ci + 2 < nchunks) issue_dma((ci + 2) * KC, buf0);
+            compute(buf1);
+        }
+    }
+
+    // ---- epilogue: lane = pixel (y0+ry, x0+rx); register quad g = 4 consecutive couts
+    const bool bn = p.bn_s != nullptr;
+    const int Hp = p.H >> 1, Wp = p.W >> 1;
+    const int x = x0 + rx, y = y0 + ry;
+    const bool inside = y < p.H;
+    char* orow = p.out + ((((size_t)b * p.H + y) * p.W + x) * p.out_cstride + p.out_coff) * 4;
+    const bool pool_lane = p.pool != nullptr && pr == 0 && (pc & 1) == 0 && y + 1 < p.H;
+    char* prow = p.pool ? p.pool + ((((size_t)b * Hp + (y >> 1)) * Wp + (x >> 1)) * p.pool_cstride + p.pool_coff) * 4 : nullptr;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int cb = n0 + 32 * mt + 8 * g + 4 * kb;
+            const float4 bias = *reinterpret_cast<const float4*>(p.bias + cb);
+            float v[4];
+            v[0] = fmaf(accc[mt][4 * g + 0], kLoInv, accm[mt][4 * g + 0]) + bias.x;
+            v[1] = fmaf(accc[mt][4 * g + 1], kLoInv, accm[mt][4 * g + 1]) + bias.y;
+            v[2] = fmaf(accc[mt][4 * g + 2], kLoInv, accm[mt][4 * g + 2]) + bias.z;
+            v[3] = fmaf(accc[mt][4 * g + 3], kLoInv, accm[mt][4 * g + 3]) + bias.w;
+            if (bn) {
+                const float4 s = *reinterpret_cast<const float4*>(p.bn_s + cb);
+                const float4 sh = *reinterpret_cast<const float4*>(p.bn_t + cb);
+                v[0] = fmaf(fmaxf(v[0], 0.f), s.x, sh.x);
+                v[1] = fmaf(fmaxf(v[1], 0.f), s.y, sh.y);
+                v[2] = fmaf(fmaxf(v[2], 0.f), s.z, sh.z);
+                v[3] = fmaf(fmaxf(v[3], 0.f), s.w, sh.w);
+            }
+            if (inside) split_store4(orow + (size_t)(cb >> 3) * 32, (cb & 7) * 2, v[0], v[1], v[2], v[3]);
+            if (p.pool != nullptr) {  // avg_pool2d(2): partners are lane^1 (x+1) and lane^16 (y+1)
+                float q[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float h = v[k] + __shfl_xor(v[k], 1);
+                    q[k] = 0.25f * (h + __shfl_xor(h, 16));
+                }
+                if (pool_lane) split_store4(prow + (size_t)(cb >> 3) * 32, (cb & 7) * 2, q[0], q[1], q[2], q[3]);
+            }
+        }
+    }
+}
+
 template <int TAPS>
 static hipError_t launch_conv_h3_t(const ConvParamsH3& p, hipStream_t stream) {
     if (p.Cin % KC != 0 || p.Cout % TN != 0 || (p.in_cstride & 7) || (p.in_coff & 7) || (p.out_cstride & 7) || (p.out_coff & 7)) return hipErrorInvalidValue;
     if (p.pool != nullptr && (((p.H | p.W) & 1) || (p.pool_cstride & 7) || (p.pool_coff & 7))) return hipErrorInvalidValue;
+    static const int dbg = [] { const char* e = getenv("LM_H3_DBG"); return e ? atoi(e) : 0; }();
+    ConvParamsH3 pd = p;
+    pd.dbg = dbg;
+    static const bool wide_ok = [] { const char* e = getenv("LM_H3_WIDE"); return !(e && e[0] == '0'); }();  // tuning knob
+    if (wide_ok && p.W % 32 == 0 && (size_t)p.H * p.W * p.in_cstride * 4 < 0x7fffffffull && (size_t)TAPS * p.Cout * p.Cin * 4 < 0x7fffffffull) {
+        const int tiles = (p.W / 32) * ((p.H + TH - 1) / TH);
+        dim3 grid((unsigned)(tiles * p.B), (unsigned)(p.Cout / TN));
+        LM_LAUNCH((conv_igemm_h3w<TAPS>), grid, dim3(1024), 0, stream, pd);
+        return hipGetLastError();
+    }
     const int tiles = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH);
     dim3 grid((unsigned)(tiles * p.B), (unsigned)(p.Cout / TN));
     LM_LAUNCH((conv_igemm_h3<TAPS>), grid, dim3(256), (H3Smem<TAPS>::BYTES), stream, p);
