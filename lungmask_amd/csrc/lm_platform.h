@@ -72,6 +72,9 @@ __device__ __forceinline__ lm_f32x16 lm_mfma_f32_32x32x2(float a, float b, lm_f3
 #define LM_LDS_WAIT6(N, a, b, c, d, e, f) \
     do {                                  \
     } while (0)
+#define LM_LDS_WAIT3(N, a, b, c) \
+    do {                         \
+    } while (0)
 #define LM_LDS_READ128(dst, ptr, OFF) (dst) = *reinterpret_cast<const lm_h16x8*>(reinterpret_cast<const char*>(ptr) + (OFF))
 #define LM_LDS_WAIT8(N, a, b, c, d, e, f, g, h) \
     do {                                        \
@@ -81,6 +84,11 @@ __device__ __forceinline__ lm_f32x16 lm_mfma_f32_32x32x2(float a, float b, lm_f3
 #define LM_LDS_WAIT6(N, a, b, c, d, e, f)                                                                         \
     do {                                                                                                          \
         asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "i"(N) : "memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
+#define LM_LDS_WAIT3(N, a, b, c)                                                                                  \
+    do {                                                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "i"(N) : "memory");                    \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
     } while (0)
 #define LM_LDS_READ128(dst, ptr, OFF)                                                                             \

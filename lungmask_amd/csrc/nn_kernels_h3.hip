@@ -191,13 +191,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(ConvParamsH3 p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Wide variant for W % 32 == 0 (every level but the 16x16 bottleneck): ONE 1024-thread workgroup per CU =
-// 16 waves (4 per SIMD, <= 128 VGPRs), tile 64 couts x 512 pixels (16 rows x 32 cols).  Wave w owns the 2-row x
-// 16-col pixel patch (w>>1, w&1) = one 32-pixel N-tile against both 32-cout M-tiles: 2 x {main, corr}
-// accumulators = 64 registers.  LDS is DOUBLE BUFFERED in two separate static objects (2 x 75 KiB): the DMA
-// of chunk i+1 is issued right after the single barrier of chunk i and lands while chunk i's MFMAs run.
-// Fragment reads are hand-issued ds_read_b128 (LM_LDS_READ128): the compiler's waitcnt pass would otherwise
-// drain the in-flight LDS-DMA in front of them.  DMA source offsets are computed once per lane.
+// Persistent variant for W % 32 == 0 (every level but the 16x16 bottleneck).
+//
+// One 512-thread workgroup per CU (8 waves = 2 per SIMD, <= 256 VGPRs) walks a list of work items
+// (64 couts x 16 rows x 32 cols of one slice) and software-pipelines ACROSS items: LDS is double buffered
+// (2 x 75 KiB) and the LDS-DMA of the next 16-channel chunk -- of this item or the first chunk of the next
+// one -- is issued right after the single barrier of the current chunk, so neither the DMA latency nor the
+// workgroup start-up is exposed between tiles (measured: ~17 us per tile with one workgroup per tile).
+// Wave w = row pair w: both 32-cout M-tiles against two 32-pixel N-tiles (rows 2w, 2w+1), {main, corr}
+// accumulators = 128 registers; 8 fragment reads feed 12 MFMAs per tap.  Fragment reads are hand-issued ds_read_b128 with immediate
+// offsets (the bank swizzle depends on the halo COLUMN only, so tap shifts are plain byte offsets); both
+// fragment streams are bank-conflict free.  The 2x2 average pool is in-lane (two N-tiles) + one lane^1 exchange.
 namespace {
 template <int TAPS>
 struct H3WSmem {
@@ -209,187 +213,228 @@ struct H3WSmem {
     static constexpr int A_PIECES = (A_ROWS * 4 + 63) / 64, W_PIECES = W_ROWS * 4 / 64;
     static constexpr int A_BYTES = A_PIECES * 1024, W_BYTES = W_PIECES * 1024;
     static constexpr int BUF_BYTES = A_BYTES + W_BYTES;
-    static constexpr int NW = 16;
+    static constexpr int NW = 8;
     static constexpr int A_PER_WAVE = (A_PIECES + NW - 1) / NW, W_PER_WAVE = (W_PIECES + NW - 1) / NW;
 };
+
+__device__ __forceinline__ float4 as_float4(const lm_h16x8& v) {
+    float4 r;
+    memcpy(&r, &v, 16);
+    return r;
+}
 }  // namespace
 
+#define H3P_TAP(DY, DX)                                                                       \
+    do {                                                                                      \
+        const int a_lo_ = a_off[DX] ^ 16;                                                     \
+        LM_LDS_READ128(f[4], as + a_off[DX], (DY) * ROWB);                                    \
+        LM_LDS_READ128(f[5], as + a_lo_, (DY) * ROWB);                                        \
+        LM_LDS_READ128(f[6], as + a_off[DX], ((DY) + 1) * ROWB);                              \
+        LM_LDS_READ128(f[7], as + a_lo_, ((DY) + 1) * ROWB);                                  \
+        LM_LDS_READ128(f[0], as + w_off, (3 * (DY) + (DX)) * (TN * 64));                      \
+        LM_LDS_READ128(f[1], as + w_off, (3 * (DY) + (DX)) * (TN * 64) + 2048);               \
+        LM_LDS_READ128(f[2], as + w_off_lo, (3 * (DY) + (DX)) * (TN * 64));                   \
+        LM_LDS_READ128(f[3], as + w_off_lo, (3 * (DY) + (DX)) * (TN * 64) + 2048);            \
+        LM_LDS_WAIT8(0, f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);                      \
+        accm[0][0] = lm_mfma_f32_32x32x16_f16(f[0], f[4], accm[0][0]);                        \
+        accc[0][0] = lm_mfma_f32_32x32x16_f16(f[0], f[5], accc[0][0]);                        \
+        accm[0][1] = lm_mfma_f32_32x32x16_f16(f[0], f[6], accm[0][1]);                        \
+        accc[0][1] = lm_mfma_f32_32x32x16_f16(f[0], f[7], accc[0][1]);                        \
+        accm[1][0] = lm_mfma_f32_32x32x16_f16(f[1], f[4], accm[1][0]);                        \
+        accc[1][0] = lm_mfma_f32_32x32x16_f16(f[1], f[5], accc[1][0]);                        \
+        accm[1][1] = lm_mfma_f32_32x32x16_f16(f[1], f[6], accm[1][1]);                        \
+        accc[1][1] = lm_mfma_f32_32x32x16_f16(f[1], f[7], accc[1][1]);                        \
+        accc[0][0] = lm_mfma_f32_32x32x16_f16(f[2], f[4], accc[0][0]);                        \
+        accc[0][1] = lm_mfma_f32_32x32x16_f16(f[2], f[6], accc[0][1]);                        \
+        accc[1][0] = lm_mfma_f32_32x32x16_f16(f[3], f[4], accc[1][0]);                        \
+        accc[1][1] = lm_mfma_f32_32x32x16_f16(f[3], f[6], accc[1][1]);                        \
+    } while (0)
+
 template <int TAPS>
-__global__ __launch_bounds__(1024) void conv_igemm_h3w(ConvParamsH3 p) {
+__global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptiles, int n_items) {
     using SM = H3WSmem<TAPS>;
-    constexpr int HALO = SM::HALO, PW = SM::PW, TWW = SM::TWW, NW = SM::NW;
-    // Two SEPARATE static LDS objects (see above).
-    __shared__ __attribute__((aligned(1024))) char buf0[SM::BUF_BYTES];
-    __shared__ __attribute__((aligned(1024))) char buf1[SM::BUF_BYTES];
+    constexpr int HALO = SM::HALO, PW = SM::PW, TWW = SM::TWW, NW = SM::NW, ROWB = PW * 64;
+    __shared__ __attribute__((aligned(1024))) char lds[2 * SM::BUF_BYTES];
+    __shared__ __attribute__((aligned(16))) float epi[2][3][TN];  // bias, bn scale, bn shift of the item (double buffered)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = lm_uniform(tid >> 6);
-    const int tiles_x = p.W / TWW, tiles_y = (p.H + TH - 1) / TH;
-    int t = blockIdx.x;
-    const int tx = t % tiles_x;
-    t /= tiles_x;
-    const int ty = t % tiles_y;
-    const int b = t / tiles_y;
-    const int x0 = tx * TWW, y0 = ty * TH, n0 = blockIdx.y * TN;
-
-    lm_f32x16 accm[2], accc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            accm[i][r] = 0.f;
-            accc[i][r] = 0.f;
-        }
-
     const int li = lane & 31, kb = lane >> 5;
-    const int pr = li >> 4, pc = li & 15;
-    const int ry = 2 * (wave >> 1) + pr, rx = 16 * (wave & 1) + pc;  // this lane's pixel inside the 16x32 tile
-    const char* __restrict__ in_b = p.in + ((size_t)b * p.H * p.W * p.in_cstride + p.in_coff) * 4;
-    const char* __restrict__ w_b = p.w + (size_t)n0 * p.Cin * 4;
+    const int rp = wave;  // row pair of the 16x32 tile owned by this wave (both 32-cout M-tiles)
 
-    // per-lane DMA source offsets: 32-bit byte offsets from ONE wave-uniform base each (=> the saddr form of
-    // global_load_lds: SGPR base + one VGPR offset); kSkip = lane issues nothing.  Out-of-image halo pixels are
-    // not DMA'd at all: their LDS slots are zeroed once, in both buffers, and never written again.
-    constexpr unsigned kSkip = 0xffffffffu;
-    unsigned offA[SM::A_PER_WAVE], offW0;
+    // ---- fragment byte offsets inside a buffer (item invariant)
+    int a_off[TAPS == 9 ? 3 : 1];
+#pragma unroll
+    for (int dx = 0; dx < (TAPS == 9 ? 3 : 1); ++dx) {
+        const int px = li + dx;
+        a_off[dx] = ((2 * rp) * PW + px) * 64 + ((2 * kb) ^ ((px >> 2) & 3)) * 16;
+    }
+    const int w_off = SM::A_BYTES + li * 64 + ((2 * kb) ^ ((li >> 2) & 3)) * 16;  // second M-tile: +2048
+    const int w_off_lo = w_off ^ 16;
+
+    // ---- DMA lane geometry (item invariant): which halo pixel / weight row this lane feeds
+    unsigned relA[SM::A_PER_WAVE];
+    int pyx[SM::A_PER_WAVE];  // py | px << 8, or -1 when the lane has nothing to do for that piece
 #pragma unroll
     for (int j = 0; j < SM::A_PER_WAVE; ++j) {
         const int piece = wave + NW * j, idx = piece * 64 + lane;
-        unsigned off = kSkip;
+        pyx[j] = -1;
+        relA[j] = 0;
         if (piece < SM::A_PIECES && idx < SM::A_ROWS * 4) {
             const int row = idx >> 2;
             const int py = row / PW, px = row - py * PW;
-            const int ls = (idx & 3) ^ ((px >> 2) & 3);  // swizzle by the halo COLUMN only: tap row shifts (dy) are then plain byte offsets
-            const int gy = y0 + py - HALO, gx = x0 + px - HALO;
-            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-                off = (unsigned)((gy * p.W + gx) * p.in_cstride * 4 + (ls >> 1) * 32 + (ls & 1) * 16);
-            } else {
-                const uint4 z = {0u, 0u, 0u, 0u};
-                *reinterpret_cast<uint4*>(buf0 + idx * 16) = z;
-                *reinterpret_cast<uint4*>(buf1 + idx * 16) = z;
-            }
+            const int ls = (idx & 3) ^ ((px >> 2) & 3);
+            relA[j] = (unsigned)((py * p.W + px) * p.in_cstride * 4 + (ls >> 1) * 32 + (ls & 1) * 16);
+            pyx[j] = py | (px << 8);
         }
-        offA[j] = off;
     }
-    {   // weight pieces wave, wave+16, wave+32: 256 rows = 4 taps apart, same cout and slot -> one VGPR + a uniform stride
+    unsigned relW0;
+    {
         const int idx = wave * 64 + lane;
         const int row = idx >> 2, ls = (idx & 3) ^ ((row >> 2) & 3);
         const int tap = row / TN, n = row - tap * TN;
-        offW0 = (unsigned)((tap * p.Cout + n) * p.Cin * 4 + (ls >> 1) * 32 + (ls & 1) * 16);
+        relW0 = (unsigned)((tap * p.Cout + n) * p.Cin * 4 + (ls >> 1) * 32 + (ls & 1) * 16);
     }
     const unsigned w_piece_stride = (unsigned)(NW * 64 / 4 / TN) * (unsigned)p.Cout * (unsigned)p.Cin * 4u;
-    auto issue_dma = [&](int c0, char* buf) {
-        const unsigned cb = (unsigned)c0 * 4u;
+    const int tiles_x = p.W / TWW;
+    const int nchunks = p.Cin / KC;
+    const bool bn = p.bn_s != nullptr;
+
+    auto decode = [&](int it, int& b, int& y0, int& x0, int& n0) {
+        const int ct = it / n_ptiles;
+        int pt = it - ct * n_ptiles;
+        const int tx = pt % tiles_x;
+        pt /= tiles_x;
+        const int tiles_y = (p.H + TH - 1) / TH;
+        const int ty = pt % tiles_y;
+        b = pt / tiles_y;
+        y0 = ty * TH;
+        x0 = tx * TWW;
+        n0 = ct * TN;
+    };
+
+    // Stage chunk c0 of item (b,y0,x0,n0) into buffer `par`.  Compiler-visible LDS stores (zero fill of the
+    // out-of-image halo slots, epilogue constants) come FIRST, while no LDS-DMA is in flight; then the DMAs.
+    auto issue = [&](int b, int y0, int x0, int n0, int c0, int par, bool first_of_item, int epar) {
+        char* buf = lds + par * SM::BUF_BYTES;
+        bool inb[SM::A_PER_WAVE];
 #pragma unroll
         for (int j = 0; j < SM::A_PER_WAVE; ++j) {
-            if (offA[j] != kSkip) lm_global_load_lds16(in_b + (size_t)(offA[j] + cb), buf + (wave + NW * j) * 1024);
+            const int gy = y0 + (pyx[j] & 0xff) - HALO, gx = x0 + (pyx[j] >> 8) - HALO;
+            inb[j] = pyx[j] >= 0 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            if (pyx[j] >= 0 && !inb[j]) {
+                const uint4 z = {0u, 0u, 0u, 0u};
+                *reinterpret_cast<uint4*>(buf + ((wave + NW * j) * 64 + lane) * 16) = z;
+            }
         }
+        if (first_of_item && tid < 3 * TN) {
+            const int arr = tid / TN, c = tid - arr * TN;
+            float v = arr == 1 ? 1.f : 0.f;
+            if (arr == 0) v = p.bias[n0 + c];
+            else if (bn) v = (arr == 1 ? p.bn_s : p.bn_t)[n0 + c];
+            epi[epar][arr][c] = v;
+        }
+        const unsigned cb = (unsigned)c0 * 4u;
+        // base of the halo tile's top-left pixel; may lie before the tensor for border tiles, only in-image lanes use it
+        const char* in_base = p.in + ((long long)b * p.H * p.W * p.in_cstride + p.in_coff) * 4 +
+                              ((long long)(y0 - HALO) * p.W + (x0 - HALO)) * (long long)p.in_cstride * 4;
+#pragma unroll
+        for (int j = 0; j < SM::A_PER_WAVE; ++j) {
+            if (inb[j]) lm_global_load_lds16(in_base + (size_t)(relA[j] + cb), buf + (wave + NW * j) * 1024);
+        }
+        const char* w_base = p.w + (size_t)n0 * p.Cin * 4;
 #pragma unroll
         for (int j = 0; j < SM::W_PER_WAVE; ++j) {
             if (wave + NW * j < SM::W_PIECES)  // wave-uniform
-                lm_global_load_lds16(w_b + (size_t)(offW0 + (unsigned)j * w_piece_stride + cb), buf + SM::A_BYTES + (wave + NW * j) * 1024);
+                lm_global_load_lds16(w_base + (size_t)(relW0 + (unsigned)j * w_piece_stride + cb), buf + SM::A_BYTES + (wave + NW * j) * 1024);
         }
     };
 
-    // Fragment addresses, all loop invariant: weights = 2 bases + tap*4096 (+2048 for the second M-tile) as
-    // immediates; activations = one base per dx (the swizzle depends on the halo column rx+dx only) + dy*PW*64.
-    const int wsw = (li >> 2) & 3;  // ((tap*64 + 32*mt + li) >> 2) & 3 == (li >> 2) & 3
-    const int w_hi_off = li * 64 + ((2 * kb) ^ wsw) * 16;  // the lo fragment sits in the neighbouring slot: address ^ 16
-    int a_hi_off[3];
+    lm_f32x16 accm[2][2], accc[2][2];  // [M-tile][N-tile = row]
+    int it = blockIdx.x;
+    if (it >= n_items) return;
+    int b, y0, x0, n0;
+    decode(it, b, y0, x0, n0);
+    int par = 0, epar = 0;
+    issue(b, y0, x0, n0, 0, par, true, epar);
+    while (true) {
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-        const int px = rx + dx, sw = (px >> 2) & 3;
-        a_hi_off[dx] = (ry * PW + px) * 64 + ((2 * kb) ^ sw) * 16;
-    }
-    auto compute = [&](const char* As) {
-        const char* Ws = As + SM::A_BYTES;
-        lm_h16x8 f[6];  // whi0 whi1 wlo0 wlo1 ahi alo
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int dy = 0; dy < (TAPS == 9 ? 3 : 1); ++dy) {
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int dx = 0; dx < (TAPS == 9 ? 3 : 1); ++dx) {
-                constexpr int ROWB = PW * 64;
-                const int tap = 3 * dy + dx;
-                // dy*ROWB and tap*4096 are folded into the ds_read immediates via the three literal cases below
-                const int a_lo = a_hi_off[dx] ^ 16;
-                if (dy == 0) {
-                    LM_LDS_READ128(f[4], As + a_hi_off[dx], 0);
-                    LM_LDS_READ128(f[5], As + a_lo, 0);
-                } else if (dy == 1) {
-                    LM_LDS_READ128(f[4], As + a_hi_off[dx], ROWB);
-                    LM_LDS_READ128(f[5], As + a_lo, ROWB);
-                } else {
-                    LM_LDS_READ128(f[4], As + a_hi_off[dx], 2 * ROWB);
-                    LM_LDS_READ128(f[5], As + a_lo, 2 * ROWB);
+                for (int r = 0; r < 16; ++r) {
+                    accm[i][j][r] = 0.f;
+                    accc[i][j][r] = 0.f;
                 }
-                const char* wh = Ws + w_hi_off + tap * (TN * 64);
-                const char* wl = Ws + (w_hi_off ^ 16) + tap * (TN * 64);
-                LM_LDS_READ128(f[0], wh, 0);
-                LM_LDS_READ128(f[1], wh, 2048);
-                LM_LDS_READ128(f[2], wl, 0);
-                LM_LDS_READ128(f[3], wl, 2048);
-                LM_LDS_WAIT6(0, f[0], f[1], f[2], f[3], f[4], f[5]);
-                accm[0] = lm_mfma_f32_32x32x16_f16(f[0], f[4], accm[0]);
-                accc[0] = lm_mfma_f32_32x32x16_f16(f[0], f[5], accc[0]);
-                accm[1] = lm_mfma_f32_32x32x16_f16(f[1], f[4], accm[1]);
-                accc[1] = lm_mfma_f32_32x32x16_f16(f[1], f[5], accc[1]);
-                accc[0] = lm_mfma_f32_32x32x16_f16(f[2], f[4], accc[0]);
-                accc[1] = lm_mfma_f32_32x32x16_f16(f[3], f[4], accc[1]);
+        const int nit = it + gridDim.x;
+        const bool have_next = nit < n_items;
+        int nb = 0, ny0 = 0, nx0 = 0, nn0 = 0;
+        if (have_next) decode(nit, nb, ny0, nx0, nn0);
+        for (int ci = 0; ci < nchunks; ++ci) {
+            __syncthreads();  // chunk ci of this item has landed in buffer `par`; everyone is done with the other buffer
+            if (ci + 1 < nchunks) issue(b, y0, x0, n0, (ci + 1) * KC, par ^ 1, false, epar);
+            else if (have_next) issue(nb, ny0, nx0, nn0, 0, par ^ 1, true, epar ^ 1);
+            const char* as = lds + par * SM::BUF_BYTES;
+            lm_h16x8 f[8];  // whi0 whi1 wlo0 wlo1 a0hi a0lo a1hi a1lo
+            if (TAPS == 9) {
+                H3P_TAP(0, 0); H3P_TAP(0, 1); H3P_TAP(0, 2);
+                H3P_TAP(1, 0); H3P_TAP(1, 1); H3P_TAP(1, 2);
+                H3P_TAP(2, 0); H3P_TAP(2, 1); H3P_TAP(2, 2);
+            } else {
+                H3P_TAP(0, 0);
             }
+            par ^= 1;
         }
-    };
-
-    // chunk loop, unrolled by two so that each half names its LDS object statically
-    const int nchunks = p.Cin / KC;
-    issue_dma(0, buf0);
-    for (int ci = 0; ci < nchunks; ci += 2) {
-        __syncthreads();  // chunk ci has landed in buf0 (LDS-DMA drained here); everyone is done reading buf1
-        if (ci + 1 < nchunks) issue_dma((ci + 1) * KC, buf1);
-        compute(buf0);
-        if (ci + 1 < nchunks) {
-            __syncthreads();  // chunk ci+1 has landed in buf1; everyone is done reading buf0
-            if (ci + 2 < nchunks) issue_dma((ci + 2) * KC, buf0);
-            compute(buf1);
-        }
-    }
-
-    // ---- epilogue: lane = pixel (y0+ry, x0+rx); register quad g = 4 consecutive couts
-    const bool bn = p.bn_s != nullptr;
-    const int Hp = p.H >> 1, Wp = p.W >> 1;
-    const int x = x0 + rx, y = y0 + ry;
-    const bool inside = y < p.H;
-    char* orow = p.out + ((((size_t)b * p.H + y) * p.W + x) * p.out_cstride + p.out_coff) * 4;
-    const bool pool_lane = p.pool != nullptr && pr == 0 && (pc & 1) == 0 && y + 1 < p.H;
-    char* prow = p.pool ? p.pool + ((((size_t)b * Hp + (y >> 1)) * Wp + (x >> 1)) * p.pool_cstride + p.pool_coff) * 4 : nullptr;
+        // ---- epilogue of this item (the first chunk of the next item is already in flight)
+        {
+            const int x = x0 + li, yb = y0 + 2 * rp;
+            const int Hp = p.H >> 1, Wp = p.W >> 1;
+            char* orow0 = p.out + ((((size_t)b * p.H + yb) * p.W + x) * p.out_cstride + p.out_coff) * 4;
+            char* orow1 = orow0 + (size_t)p.W * p.out_cstride * 4;
+            char* prow = p.pool ? p.pool + ((((size_t)b * Hp + (yb >> 1)) * Wp + (x >> 1)) * p.pool_cstride + p.pool_coff) * 4 : nullptr;
+            const bool r0 = yb < p.H, r1 = yb + 1 < p.H;
+            const char* ep = reinterpret_cast<const char*>(&epi[epar][0][0]);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+            for (int mg = 0; mg < 8; ++mg) {
+                const int mt = mg >> 2, g = mg & 3;
+                const int cl = 32 * mt + 8 * g + 4 * kb;  // first of 4 consecutive local output channels
+                lm_h16x8 e0, e1, e2;
+                LM_LDS_READ128(e0, ep + cl * 4, 0);
+                LM_LDS_READ128(e1, ep + cl * 4, TN * 4);
+                LM_LDS_READ128(e2, ep + cl * 4, 2 * TN * 4);
+                LM_LDS_WAIT3(0, e0, e1, e2);
+                const float4 bias = as_float4(e0), s = as_float4(e1), sh = as_float4(e2);
+                const float bb[4] = {bias.x, bias.y, bias.z, bias.w}, ss[4] = {s.x, s.y, s.z, s.w}, tt[4] = {sh.x, sh.y, sh.z, sh.w};
+                float v[2][4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int cb = n0 + 32 * mt + 8 * g + 4 * kb;
-            const float4 bias = *reinterpret_cast<const float4*>(p.bias + cb);
-            float v[4];
-            v[0] = fmaf(accc[mt][4 * g + 0], kLoInv, accm[mt][4 * g + 0]) + bias.x;
-            v[1] = fmaf(accc[mt][4 * g + 1], kLoInv, accm[mt][4 * g + 1]) + bias.y;
-            v[2] = fmaf(accc[mt][4 * g + 2], kLoInv, accm[mt][4 * g + 2]) + bias.z;
-            v[3] = fmaf(accc[mt][4 * g + 3], kLoInv, accm[mt][4 * g + 3]) + bias.w;
-            if (bn) {
-                const float4 s = *reinterpret_cast<const float4*>(p.bn_s + cb);
-                const float4 sh = *reinterpret_cast<const float4*>(p.bn_t + cb);
-                v[0] = fmaf(fmaxf(v[0], 0.f), s.x, sh.x);
-                v[1] = fmaf(fmaxf(v[1], 0.f), s.y, sh.y);
-                v[2] = fmaf(fmaxf(v[2], 0.f), s.z, sh.z);
-                v[3] = fmaf(fmaxf(v[3], 0.f), s.w, sh.w);
-            }
-            if (inside) split_store4(orow + (size_t)(cb >> 3) * 32, (cb & 7) * 2, v[0], v[1], v[2], v[3]);
-            if (p.pool != nullptr) {  // avg_pool2d(2): partners are lane^1 (x+1) and lane^16 (y+1)
-                float q[4];
+                for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float h = v[k] + __shfl_xor(v[k], 1);
-                    q[k] = 0.25f * (h + __shfl_xor(h, 16));
+                    for (int k = 0; k < 4; ++k) {
+                        float t = fmaf(accc[mt][nt][4 * g + k], kLoInv, accm[mt][nt][4 * g + k]) + bb[k];
+                        if (bn) t = fmaf(fmaxf(t, 0.f), ss[k], tt[k]);
+                        v[nt][k] = t;
+                    }
+                const int cg = n0 + cl;
+                if (r0) split_store4(orow0 + (size_t)(cg >> 3) * 32, (cg & 7) * 2, v[0][0], v[0][1], v[0][2], v[0][3]);
+                if (r1) split_store4(orow1 + (size_t)(cg >> 3) * 32, (cg & 7) * 2, v[1][0], v[1][1], v[1][2], v[1][3]);
+                if (p.pool != nullptr) {  // avg_pool2d(2): rows yb, yb+1 are this lane's two N-tiles; x+1 is lane^1
+                    float q[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float h = v[0][k] + v[1][k];
+                        q[k] = 0.25f * (h + __shfl_xor(h, 1));
+                    }
+                    if ((li & 1) == 0 && r1) split_store4(prow + (size_t)(cg >> 3) * 32, (cg & 7) * 2, q[0], q[1], q[2], q[3]);
                 }
-                if (pool_lane) split_store4(prow + (size_t)(cb >> 3) * 32, (cb & 7) * 2, q[0], q[1], q[2], q[3]);
             }
         }
+        if (!have_next) break;
+        it = nit;
+        b = nb;
+        y0 = ny0;
+        x0 = nx0;
+        n0 = nn0;
+        epar ^= 1;
     }
 }
 
@@ -402,9 +447,19 @@ static hipError_t launch_conv_h3_t(const ConvParamsH3& p, hipStream_t stream) {
     pd.dbg = dbg;
     static const bool wide_ok = [] { const char* e = getenv("LM_H3_WIDE"); return !(e && e[0] == '0'); }();  // tuning knob
     if (wide_ok && p.W % 32 == 0 && (size_t)p.H * p.W * p.in_cstride * 4 < 0x7fffffffull && (size_t)TAPS * p.Cout * p.Cin * 4 < 0x7fffffffull) {
-        const int tiles = (p.W / 32) * ((p.H + TH - 1) / TH);
-        dim3 grid((unsigned)(tiles * p.B), (unsigned)(p.Cout / TN));
-        LM_LAUNCH((conv_igemm_h3w<TAPS>), grid, dim3(1024), 0, stream, pd);
+        const int n_ptiles = (p.W / 32) * ((p.H + TH - 1) / TH) * p.B;
+        const int n_items = n_ptiles * (p.Cout / TN);
+        static const int n_cu = [] {
+#ifdef LM_EMU_BUILD
+            return 4;
+#else
+            int dev = 0, n = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+            return n > 0 ? n : 256;
+#endif
+        }();
+        const unsigned blocks = (unsigned)std::min(n_items, n_cu);
+        LM_LAUNCH((conv_igemm_h3p<TAPS>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items);
         return hipGetLastError();
     }
     const int tiles = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH);
