@@ -32,6 +32,19 @@ __device__ __forceinline__ lm_f32x16 lm_mfma_f32_32x32x16_f16(lm_h16x8 a, lm_h16
 #endif
 }
 
+// Ordering point between LDS writes and reads of OTHER lanes of the same wave.  The hardware executes a
+// wave's LDS instructions in order, so nothing is emitted on the GPU; the test emulator runs lanes as
+// independent fibres and needs the rendezvous.
+__device__ __forceinline__ void lm_wave_lds_fence() {
+#ifdef LM_EMU_BUILD
+    lm_emu::wave_sync();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
 // A value the program knows to be wave-uniform, made provably so for the compiler (SGPR instead of a
 // per-lane VGPR + waterfall loop).
 __device__ __forceinline__ int lm_uniform(int x) {
@@ -63,9 +76,43 @@ __device__ __forceinline__ lm_f32x16 lm_mfma_f32_32x32x2(float a, float b, lm_f3
 #endif
 }
 
+// 4-byte variant (global_load_lds_dword): 64 lanes fill 256 contiguous LDS bytes.
+__device__ __forceinline__ void lm_global_load_lds4(const void* gsrc, void* lds_wave_base) {
+#ifdef LM_EMU_BUILD
+    memcpy((char*)lds_wave_base + (lm_emu::linear_tid() & 63) * 4, gsrc, 4);
+#else
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+#endif
+}
+
+// fp32 x4 -> split-f16: hi = f16(v), lo = f16((v - hi) * 2048), each packed as 4 halves (8 bytes).
+// The vector form makes hipcc emit v_cvt_pk_f16_f32 / v_pk_add_f32 / v_pk_mul_f32 (3 VALU per value).
+__device__ __forceinline__ void lm_split4(float v0, float v1, float v2, float v3, uint2* hi, uint2* lo) {
+#ifdef LM_EMU_BUILD
+    lm_h16 h[4] = {lm_f2h(v0), lm_f2h(v1), lm_f2h(v2), lm_f2h(v3)};
+    lm_h16 l[4] = {lm_f2h((v0 - lm_h2f(h[0])) * 2048.0f), lm_f2h((v1 - lm_h2f(h[1])) * 2048.0f),
+                   lm_f2h((v2 - lm_h2f(h[2])) * 2048.0f), lm_f2h((v3 - lm_h2f(h[3])) * 2048.0f)};
+    memcpy(hi, h, 8);
+    memcpy(lo, l, 8);
+#else
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 v = {v0, v1, v2, v3};
+    const h4 h = __builtin_convertvector(v, h4);
+    const f4 r = (v - __builtin_convertvector(h, f4)) * 2048.0f;
+    const h4 l = __builtin_convertvector(r, h4);
+    __builtin_memcpy(hi, &h, 8);
+    __builtin_memcpy(lo, &l, 8);
+#endif
+}
+
 // 16-byte LDS reads that the compiler's waitcnt pass cannot see (so it does not drain an in-flight LDS-DMA
 // in front of them), with an explicit counted wait that names every destination register.
 #ifdef LM_EMU_BUILD
+#define LM_KEEP_ALIVE2(a, b) \
+    do {                     \
+    } while (0)
 #define LM_OPAQUE3(a, b, c) \
     do {                    \
     } while (0)
@@ -80,6 +127,7 @@ __device__ __forceinline__ lm_f32x16 lm_mfma_f32_32x32x2(float a, float b, lm_f3
     do {                                        \
     } while (0)
 #else
+#define LM_KEEP_ALIVE2(a, b) asm volatile("" ::"v"(a), "v"(b))
 #define LM_OPAQUE3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
 #define LM_LDS_WAIT6(N, a, b, c, d, e, f)                                                                         \
     do {                                                                                                          \

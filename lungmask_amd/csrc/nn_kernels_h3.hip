@@ -32,15 +32,15 @@ namespace {
 constexpr int TH = 16, TW = 16, TN = 64, KC = 16;
 constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
 
+// Staging through LDS reads back, as 16-byte units, bytes that were written as 8-byte units: these accesses
+// must be exempt from type-based alias analysis or the loads may be hoisted above the stores.
+typedef uint2 __attribute__((may_alias)) uint2_a;
+typedef uint4 __attribute__((may_alias)) uint4_a;
+
 __device__ __forceinline__ void split_store4(char* group_base, int half_off_bytes, float v0, float v1, float v2, float v3) {
     // writes 4 consecutive channels (hi at +0, lo at +16 of the 32-byte group); half_off_bytes = (c & 7) * 2
-    const lm_h16 h0 = lm_f2h(v0), h1 = lm_f2h(v1), h2 = lm_f2h(v2), h3 = lm_f2h(v3);
-    const lm_h16 l0 = lm_f2h((v0 - lm_h2f(h0)) * kLoScale), l1 = lm_f2h((v1 - lm_h2f(h1)) * kLoScale);
-    const lm_h16 l2 = lm_f2h((v2 - lm_h2f(h2)) * kLoScale), l3 = lm_f2h((v3 - lm_h2f(h3)) * kLoScale);
-    lm_h16 hh[4] = {h0, h1, h2, h3}, ll[4] = {l0, l1, l2, l3};
     uint2 ph, plo;
-    memcpy(&ph, hh, 8);
-    memcpy(&plo, ll, 8);
+    lm_split4(v0, v1, v2, v3, &ph, &plo);
     *reinterpret_cast<uint2*>(group_base + half_off_bytes) = ph;
     *reinterpret_cast<uint2*>(group_base + 16 + half_off_bytes) = plo;
 }
@@ -254,7 +254,11 @@ template <int TAPS>
 __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptiles, int n_items) {
     using SM = H3WSmem<TAPS>;
     constexpr int HALO = SM::HALO, PW = SM::PW, TWW = SM::TWW, NW = SM::NW, ROWB = PW * 64;
-    __shared__ __attribute__((aligned(1024))) char lds[2 * SM::BUF_BYTES];
+    constexpr int PSTR = 272;                   // staged pixel stride of the epilogue: 256 B of split data + 16 B pad
+    constexpr int STAGE_BYTES = NW * 32 * PSTR;  // one 32-pixel row per wave
+    // The epilogue staging area reuses the DMA buffer of the last chunk when it fits (3x3: 75 KiB), else it is extra.
+    constexpr int STAGE_EXTRA = STAGE_BYTES <= SM::BUF_BYTES ? 0 : STAGE_BYTES;
+    __shared__ __attribute__((aligned(1024))) char lds[2 * SM::BUF_BYTES + STAGE_EXTRA];
     __shared__ __attribute__((aligned(16))) float epi[2][3][TN];  // bias, bn scale, bn shift of the item (double buffered)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = lm_uniform(tid >> 6);
@@ -326,14 +330,11 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                 *reinterpret_cast<uint4*>(buf + ((wave + NW * j) * 64 + lane) * 16) = z;
             }
         }
-        if (first_of_item && tid < 3 * TN) {
-            const int arr = tid / TN, c = tid - arr * TN;
-            float v = arr == 1 ? 1.f : 0.f;
-            if (arr == 0) v = p.bias[n0 + c];
-            else if (bn) v = (arr == 1 ? p.bn_s : p.bn_t)[n0 + c];
-            epi[epar][arr][c] = v;
-        }
         const unsigned cb = (unsigned)c0 * 4u;
+        if (first_of_item && wave < (bn ? 3 : 1)) {  // epilogue constants of the item: 64 floats per array = one 4-byte DMA per wave
+            const float* src = wave == 0 ? p.bias : (wave == 1 ? p.bn_s : p.bn_t);
+            lm_global_load_lds4(src + n0 + lane, &epi[epar][wave][0]);
+        }
         // base of the halo tile's top-left pixel; may lie before the tensor for border tiles, only in-image lanes use it
         const char* in_base = p.in + ((long long)b * p.H * p.W * p.in_cstride + p.in_coff) * 4 +
                               ((long long)(y0 - HALO) * p.W + (x0 - HALO)) * (long long)p.in_cstride * 4;
@@ -352,6 +353,10 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
     lm_f32x16 accm[2][2], accc[2][2];  // [M-tile][N-tile = row]
     int it = blockIdx.x;
     if (it >= n_items) return;
+    if (!bn && tid < 2 * TN) {  // no BatchNorm (decoder 1x1): identity constants, never overwritten
+        epi[0][1 + tid / TN][tid % TN] = tid < TN ? 1.f : 0.f;
+        epi[1][1 + tid / TN][tid % TN] = tid < TN ? 1.f : 0.f;
+    }
     int b, y0, x0, n0;
     decode(it, b, y0, x0, n0);
     int par = 0, epar = 0;
@@ -372,8 +377,10 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
         if (have_next) decode(nit, nb, ny0, nx0, nn0);
         for (int ci = 0; ci < nchunks; ++ci) {
             __syncthreads();  // chunk ci of this item has landed in buffer `par`; everyone is done with the other buffer
-            if (ci + 1 < nchunks) issue(b, y0, x0, n0, (ci + 1) * KC, par ^ 1, false, epar);
-            else if (have_next) issue(nb, ny0, nx0, nn0, 0, par ^ 1, true, epar ^ 1);
+            if (!(p.dbg & 2)) {
+                if (ci + 1 < nchunks) issue(b, y0, x0, n0, (ci + 1) * KC, par ^ 1, false, epar);
+                else if (have_next) issue(nb, ny0, nx0, nn0, 0, par ^ 1, true, epar ^ 1);
+            }
             const char* as = lds + par * SM::BUF_BYTES;
             lm_h16x8 f[8];  // whi0 whi1 wlo0 wlo1 a0hi a0lo a1hi a1lo
             if (TAPS == 9) {
@@ -386,45 +393,71 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
             par ^= 1;
         }
         // ---- epilogue of this item (the first chunk of the next item is already in flight)
-        {
-            const int x = x0 + li, yb = y0 + 2 * rp;
+        if (p.dbg & 1) {  // ablation: keep the accumulators alive, skip the epilogue
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) LM_KEEP_ALIVE2(accm[i][j], accc[i][j]);
+        } else {
+            // All waves are done with the buffer of the last chunk: it becomes the staging area that turns the
+            // accumulator layout (lane = pixel, 8 bytes per 4 couts: 64 scattered lines per store) into full
+            // 256-byte pixel rows written 16 bytes per lane (the scattered form cost ~10 us per tile in the TA).
+            __syncthreads();
+            char* stage = (STAGE_EXTRA ? lds + 2 * SM::BUF_BYTES : lds + (par ^ 1) * SM::BUF_BYTES) + wave * (32 * PSTR);
+            const int yb = y0 + 2 * rp;
             const int Hp = p.H >> 1, Wp = p.W >> 1;
-            char* orow0 = p.out + ((((size_t)b * p.H + yb) * p.W + x) * p.out_cstride + p.out_coff) * 4;
-            char* orow1 = orow0 + (size_t)p.W * p.out_cstride * 4;
-            char* prow = p.pool ? p.pool + ((((size_t)b * Hp + (yb >> 1)) * Wp + (x >> 1)) * p.pool_cstride + p.pool_coff) * 4 : nullptr;
-            const bool r0 = yb < p.H, r1 = yb + 1 < p.H;
+            char* prow = p.pool ? p.pool + ((((size_t)b * Hp + (yb >> 1)) * Wp + ((x0 + li) >> 1)) * p.pool_cstride + p.pool_coff) * 4 : nullptr;
             const char* ep = reinterpret_cast<const char*>(&epi[epar][0][0]);
+            float pl[8][4];  // row yb + row yb+1 (for the pool)
 #pragma unroll
-            for (int mg = 0; mg < 8; ++mg) {
-                const int mt = mg >> 2, g = mg & 3;
-                const int cl = 32 * mt + 8 * g + 4 * kb;  // first of 4 consecutive local output channels
-                lm_h16x8 e0, e1, e2;
-                LM_LDS_READ128(e0, ep + cl * 4, 0);
-                LM_LDS_READ128(e1, ep + cl * 4, TN * 4);
-                LM_LDS_READ128(e2, ep + cl * 4, 2 * TN * 4);
-                LM_LDS_WAIT3(0, e0, e1, e2);
-                const float4 bias = as_float4(e0), s = as_float4(e1), sh = as_float4(e2);
-                const float bb[4] = {bias.x, bias.y, bias.z, bias.w}, ss[4] = {s.x, s.y, s.z, s.w}, tt[4] = {sh.x, sh.y, sh.z, sh.w};
-                float v[2][4];
+            for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                for (int mg = 0; mg < 8; ++mg) {
+                    const int mt = mg >> 2, g = mg & 3;
+                    const int cl = 32 * mt + 8 * g + 4 * kb;  // first of 4 consecutive local output channels
+                    lm_h16x8 e0, e1, e2;
+                    LM_LDS_READ128(e0, ep + cl * 4, 0);
+                    LM_LDS_READ128(e1, ep + cl * 4, TN * 4);
+                    LM_LDS_READ128(e2, ep + cl * 4, 2 * TN * 4);
+                    LM_LDS_WAIT3(0, e0, e1, e2);
+                    const float4 bias = as_float4(e0), s = as_float4(e1), sh = as_float4(e2);
+                    const float bb[4] = {bias.x, bias.y, bias.z, bias.w}, ss[4] = {s.x, s.y, s.z, s.w}, tt[4] = {sh.x, sh.y, sh.z, sh.w};
+                    float v[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         float t = fmaf(accc[mt][nt][4 * g + k], kLoInv, accm[mt][nt][4 * g + k]) + bb[k];
                         if (bn) t = fmaf(fmaxf(t, 0.f), ss[k], tt[k]);
-                        v[nt][k] = t;
+                        v[k] = t;
+                        pl[mg][k] = nt == 0 ? t : pl[mg][k] + t;
                     }
-                const int cg = n0 + cl;
-                if (r0) split_store4(orow0 + (size_t)(cg >> 3) * 32, (cg & 7) * 2, v[0][0], v[0][1], v[0][2], v[0][3]);
-                if (r1) split_store4(orow1 + (size_t)(cg >> 3) * 32, (cg & 7) * 2, v[1][0], v[1][1], v[1][2], v[1][3]);
-                if (p.pool != nullptr) {  // avg_pool2d(2): rows yb, yb+1 are this lane's two N-tiles; x+1 is lane^1
+                    uint2 ph, plo;
+                    lm_split4(v[0], v[1], v[2], v[3], &ph, &plo);
+                    char* d = stage + li * PSTR + (cl >> 3) * 32 + (cl & 7) * 2;
+                    *reinterpret_cast<uint2_a*>(d) = ph;
+                    *reinterpret_cast<uint2_a*>(d + 16) = plo;
+                }
+                // the wave's own 32 pixels x 256 B are now in LDS (same-wave LDS ops are ordered): stream them out
+                lm_wave_lds_fence();
+                const int y = yb + nt;
+                if (y < p.H) {
+                    char* orow = p.out + ((((size_t)b * p.H + y) * p.W + x0) * p.out_cstride + p.out_coff + n0) * 4;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int q = i * 64 + lane, px = q >> 4, part = q & 15;
+                        const uint4 val = *reinterpret_cast<const uint4_a*>(stage + px * PSTR + part * 16);
+                        *reinterpret_cast<uint4_a*>(orow + (size_t)px * p.out_cstride * 4 + part * 16) = val;
+                    }
+                }
+                lm_wave_lds_fence();  // the staging rows are rewritten by the next row
+            }
+            if (p.pool != nullptr) {  // avg_pool2d(2): rows yb, yb+1 summed above; x+1 is lane^1
+#pragma unroll
+                for (int mg = 0; mg < 8; ++mg) {
+                    const int cg = n0 + 32 * (mg >> 2) + 8 * (mg & 3) + 4 * kb;
                     float q[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float h = v[0][k] + v[1][k];
-                        q[k] = 0.25f * (h + __shfl_xor(h, 1));
-                    }
-                    if ((li & 1) == 0 && r1) split_store4(prow + (size_t)(cg >> 3) * 32, (cg & 7) * 2, q[0], q[1], q[2], q[3]);
+                    for (int k = 0; k < 4; ++k) q[k] = 0.25f * (pl[mg][k] + __shfl_xor(pl[mg][k], 1));
+                    if ((li & 1) == 0 && yb + 1 < p.H) split_store4(prow + (size_t)(cg >> 3) * 32, (cg & 7) * 2, q[0], q[1], q[2], q[3]);
                 }
             }
         }
