@@ -122,6 +122,13 @@ int lm_apply_dev(lm_engine* e, int slot, int fill_slot, const void* vol_dev, int
 int lm_apply_host(lm_engine* e, int slot, int fill_slot, const void* vol_host, int dtype, int n, int h, int w,
                   int batch_size, int volume_postprocessing, uint8_t* out_host);
 
+/* The batch loop of mask.py:173-187 in one call: n slices in batches of batch_size.  With two forward
+ * lanes (default; lm_set_streams(e, 1) disables) consecutive batches alternate between two HIP streams and
+ * workspaces so that one batch's kernel tails are filled by the next batch's work; results are identical. */
+int lm_forward_batches_dev(lm_engine* e, int slot, const float* x_dev, int n, int h, int w, int batch_size,
+                           uint8_t* labels_dev);
+int lm_set_streams(lm_engine* e, int n);
+
 /* Per-kernel timing of the network launches since the last reset (HIP events on
  * the engine stream; enabled with lm_profile_enable(e, 1)).  Returns the number
  * of distinct kernel kinds; fills up to `cap` entries. */

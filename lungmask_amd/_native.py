@@ -64,6 +64,8 @@ class Library:
         L.lm_model_classes.argtypes = [C.c_void_p, C.c_int]
         L.lm_forward_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.lm_set_precision.argtypes = [C.c_void_p, C.c_int]
+        L.lm_set_streams.argtypes = [C.c_void_p, C.c_int]
+        L.lm_forward_batches_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.lm_preprocess_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_int] * 5 + [C.c_void_p] * 4
         L.lm_reshape_mask_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
         L.lm_postprocess_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]
@@ -191,6 +193,9 @@ class Engine:
         """'f32' / 0: exact fp32 matrix ops;  'split_f16' / 1: 3-product split-f16."""
         m = {"f32": 0, "split_f16": 1}.get(mode, mode)
         self.L.check(self.L.lib.lm_set_precision(self.h, int(m)), "lm_set_precision")
+
+    def set_streams(self, n: int):
+        self.L.check(self.L.lib.lm_set_streams(self.h, int(n)), "lm_set_streams")
 
     def forward_dev(self, slot: int, x: DeviceArray, labels: Optional[DeviceArray] = None, logp: Optional[DeviceArray] = None):
         b, h, w = x.shape

@@ -35,6 +35,11 @@ int lm_engine_create(lm_engine** out, int device_id) {
         delete e;
         return LM_ERR_DEVICE;
     }
+    if (hipStreamCreate(&e->stream2) != hipSuccess || hipEventCreate(&e->ev_fork) != hipSuccess || hipEventCreate(&e->ev_join) != hipSuccess) {
+        set_error("creating the second forward lane failed");
+        e->stream2 = nullptr;
+        e->n_streams = 1;
+    }
     *out = e;
     return LM_OK;
 }
@@ -45,8 +50,13 @@ void lm_engine_destroy(lm_engine* e) {
     (void)hipStreamSynchronize(e->stream);
     e->prof.release();
     for (auto& m : e->models) m.release();
+    if (e->stream2) (void)hipStreamSynchronize(e->stream2);
     if (e->zero_page) (void)hipFree(e->zero_page);
     e->nn.release();
+    e->nn2.release();
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    if (e->stream2) (void)hipStreamDestroy(e->stream2);
     e->post.release();
     e->app.release();
     (void)hipStreamDestroy(e->stream);
@@ -55,6 +65,7 @@ void lm_engine_destroy(lm_engine* e) {
 
 int lm_engine_sync(lm_engine* e) {
     if (!e) return LM_ERR_INVALID;
+    if (e->stream2) LM_HIP(hipStreamSynchronize(e->stream2));
     LM_HIP(hipStreamSynchronize(e->stream));
     return LM_OK;
 }
@@ -101,6 +112,20 @@ int lm_set_precision(lm_engine* e, int mode) {
     }
     e->precision = mode;
     return LM_OK;
+}
+
+int lm_set_streams(lm_engine* e, int n) {
+    if (!e || n < 1 || n > 2) {
+        set_error("lm_set_streams: 1 or 2");
+        return LM_ERR_INVALID;
+    }
+    e->n_streams = (n == 2 && e->stream2) ? 2 : 1;
+    return LM_OK;
+}
+
+int lm_forward_batches_dev(lm_engine* e, int slot, const float* x_dev, int n, int h, int w, int batch_size, uint8_t* labels_dev) {
+    if (!e || !x_dev || !labels_dev || n < 0) return LM_ERR_INVALID;
+    return forward_batches(e, slot, x_dev, n, h, w, batch_size, labels_dev);
 }
 
 int lm_forward_dev(lm_engine* e, int slot, const float* x_dev, int b, int h, int w, uint8_t* labels_dev, float* logp_dev) {

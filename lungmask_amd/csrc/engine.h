@@ -113,6 +113,13 @@ struct lm_engine {
     hipStream_t stream = nullptr;
     lm::Model models[4];
     lm::NNWorkspace nn;
+    // second forward lane: consecutive slice batches alternate between two streams / workspaces so that the
+    // tail of one batch's kernels (tile quantisation, launch gaps, the small bandwidth-bound kernels) is filled
+    // by the other batch's work
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    lm::NNWorkspace nn2;
+    int n_streams = 2;
     lm::PostWorkspace post;
     lm::ApplyWorkspace app;
     lm::PostInfo post_info;
@@ -123,7 +130,9 @@ struct lm_engine {
 
 namespace lm {
 int model_load(lm_engine* e, int slot, const lm_tensor* tensors, int n);
-int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t* labels, float* logp);
+int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t* labels, float* logp, int lane = 0);
+// n slices in batches of `batch` (mask.py:173-187), batches alternating over the engine's forward lanes
+int forward_batches(lm_engine* e, int slot, const float* x, int n, int H, int W, int batch, uint8_t* labels);
 int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spare, int n_spare, int skip_below);
 int apply_volume(lm_engine* e, int slot, int fill_slot, const void* vol_dev, int dtype, int n, int h, int w, int batch_size,
                  int volume_postprocessing, uint8_t* out_dev);

@@ -1,5 +1,6 @@
 // Model loading (mask.py:38-68) and the layer schedule of UNet.forward
 // (resunet.py:58-70) on top of the kernels in nn_kernels.hip.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -266,6 +267,7 @@ namespace {
 
 struct Fwd {
     lm_engine* e;
+    hipStream_t st;
     int B;
     int kc3, kc1, kfirst, kup, khead;
 
@@ -299,7 +301,7 @@ struct Fwd {
             snprintf(nm, sizeof nm, "%s%s/H%d_Ci%d_Co%d", L.taps == 9 ? "conv3x3_igemm_" : "conv1x1_igemm_", e->precision == 1 ? "h3" : "f32", H, L.cin, L.cout);
             kind = e->prof.kind_id(nm);
         }
-        e->prof.begin(e->stream, kind, flops, bytes);
+        e->prof.begin(st, kind, flops, bytes);
         hipError_t err;
         if (e->precision == 1) {
             ConvParamsH3 q{};
@@ -322,11 +324,11 @@ struct Fwd {
             q.W = W;
             q.Cin = L.cin;
             q.Cout = L.cout;
-            err = (L.taps == 9) ? launch_conv3x3_h3(q, e->stream) : launch_conv1x1_h3(q, e->stream);
+            err = (L.taps == 9) ? launch_conv3x3_h3(q, st) : launch_conv1x1_h3(q, st);
         } else {
-            err = (L.taps == 9) ? launch_conv3x3(p, e->stream) : launch_conv1x1(p, e->stream);
+            err = (L.taps == 9) ? launch_conv3x3(p, st) : launch_conv1x1(p, st);
         }
-        e->prof.end(e->stream);
+        e->prof.end(st);
         if (err != hipSuccess) {
             set_error("conv launch failed: %s (Cin=%d Cout=%d H=%d W=%d)", hipGetErrorString(err), L.cin, L.cout, H, W);
             return LM_ERR_DEVICE;
@@ -337,7 +339,7 @@ struct Fwd {
 
 }  // namespace
 
-int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t* labels, float* logp) {
+int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t* labels, float* logp, int lane) {
     if (slot < 0 || slot >= 4 || !e->models[slot].loaded) {
         set_error("model slot %d is empty", slot);
         return LM_ERR_NOMODEL;
@@ -347,7 +349,8 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
         return LM_ERR_INVALID;
     }
     const Model& md = e->models[slot];
-    NNWorkspace& ws = e->nn;
+    NNWorkspace& ws = lane ? e->nn2 : e->nn;
+    hipStream_t stream = lane ? e->stream2 : e->stream;
     const size_t px = (size_t)B * H * W;
     LM_TRY(ws.t1.reserve(px * 64 * 4));
     LM_TRY(ws.t2.reserve(px * 16 * 4));
@@ -358,7 +361,7 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
     }
     float *t1 = ws.t1.as<float>(), *t2 = ws.t2.as<float>(), *t3 = ws.t3.as<float>();
     const bool h3 = e->precision == 1;
-    Fwd f{e, B, e->prof.kind_id(h3 ? "conv3x3_igemm_h3" : "conv3x3_igemm_f32"), e->prof.kind_id(h3 ? "conv1x1_igemm_h3" : "conv1x1_igemm_f32"),
+    Fwd f{e, stream, B, e->prof.kind_id(h3 ? "conv3x3_igemm_h3" : "conv3x3_igemm_f32"), e->prof.kind_id(h3 ? "conv1x1_igemm_h3" : "conv1x1_igemm_f32"),
           e->prof.kind_id("first_conv"), e->prof.kind_id("upsample2x"), e->prof.kind_id("head_argmax")};
     if (h3 && !e->zero_page) {
         void* zp = nullptr;
@@ -370,9 +373,9 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
     // ---- encoder (resunet.py:60-64)
     {
         FirstConvParams p{x, md.first.w, md.first.bias, md.first.bn_s, md.first.bn_t, t1, 64, 0, B, H, W};
-        e->prof.begin(e->stream, f.kfirst, 2.0 * px * 64 * 9, 4.0 * px * 65);
-        hipError_t err = h3 ? launch_first_conv_h3(p, e->stream) : launch_first_conv(p, e->stream);
-        e->prof.end(e->stream);
+        e->prof.begin(stream, f.kfirst, 2.0 * px * 64 * 9, 4.0 * px * 65);
+        hipError_t err = h3 ? launch_first_conv_h3(p, stream) : launch_first_conv(p, stream);
+        e->prof.end(stream);
         if (err != hipSuccess) {
             set_error("first_conv launch failed: %s", hipGetErrorString(err));
             return LM_ERR_DEVICE;
@@ -395,9 +398,9 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
         {
             UpsampleParams p{t2, ws.cat[lvl].as<float>(), 2 * c, 0, B, h / 2, w / 2, c};
             const double opx = (double)B * h * w;
-            e->prof.begin(e->stream, f.kup, 0, 4.0 * (opx * c + opx / 4 * c));
-            hipError_t err = h3 ? launch_upsample2x_h3(p, e->stream) : launch_upsample2x(p, e->stream);
-            e->prof.end(e->stream);
+            e->prof.begin(stream, f.kup, 0, 4.0 * (opx * c + opx / 4 * c));
+            hipError_t err = h3 ? launch_upsample2x_h3(p, stream) : launch_upsample2x(p, stream);
+            e->prof.end(stream);
             if (err != hipSuccess) {
                 set_error("upsample launch failed: %s", hipGetErrorString(err));
                 return LM_ERR_DEVICE;
@@ -409,13 +412,34 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
     // ---- head (resunet.py:69-70, mask.py:184-186)
     {
         HeadParams p{t3, md.head_w, md.head_b, labels, logp, B, H, W, md.n_classes};
-        e->prof.begin(e->stream, f.khead, 2.0 * px * 64 * md.n_classes, 4.0 * px * 64 + px);
-        hipError_t err = h3 ? launch_head_h3(p, e->stream) : launch_head(p, e->stream);
-        e->prof.end(e->stream);
+        e->prof.begin(stream, f.khead, 2.0 * px * 64 * md.n_classes, 4.0 * px * 64 + px);
+        hipError_t err = h3 ? launch_head_h3(p, stream) : launch_head(p, stream);
+        e->prof.end(stream);
         if (err != hipSuccess) {
             set_error("head launch failed: %s", hipGetErrorString(err));
             return LM_ERR_DEVICE;
         }
+    }
+    return LM_OK;
+}
+
+
+int forward_batches(lm_engine* e, int slot, const float* x, int n, int H, int W, int batch, uint8_t* labels) {
+    if (batch <= 0) batch = 20;
+    const size_t px = (size_t)H * W;
+    const bool dual = e->n_streams > 1 && e->stream2 != nullptr && n > batch;
+    if (dual) {  // lane 1 must see everything enqueued so far on the main stream (pre-processing)
+        LM_HIP(hipEventRecord(e->ev_fork, e->stream));
+        LM_HIP(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
+    }
+    int k = 0;
+    for (int b0 = 0; b0 < n; b0 += batch, ++k) {
+        const int b = std::min(batch, n - b0);
+        LM_TRY(forward(e, slot, x + (size_t)b0 * px, b, H, W, labels + (size_t)b0 * px, nullptr, dual ? (k & 1) : 0));
+    }
+    if (dual) {
+        LM_HIP(hipEventRecord(e->ev_join, e->stream2));
+        LM_HIP(hipStreamWaitEvent(e->stream, e->ev_join, 0));
     }
     return LM_OK;
 }

@@ -280,10 +280,7 @@ int inference(lm_engine* e, int slot, const void* vol, int dtype, int n, int h, 
             LM_K(launch_resample_norm(rp, e->stream));
         }
     }
-    for (int b0 = 0; b0 < n; b0 += batch) {  // mask.py:173-187
-        const int b = std::min(batch, n - b0);
-        LM_TRY(forward(e, slot, a.xf.as<float>() + (size_t)b0 * R * R, b, R, R, a.labels.as<uint8_t>() + (size_t)b0 * R * R, nullptr));
-    }
+    LM_TRY(forward_batches(e, slot, a.xf.as<float>(), n, R, R, batch, a.labels.as<uint8_t>()));  // mask.py:173-187
     if (vol_post) LM_TRY(postprocess(e, a.labels.as<uint8_t>(), n, R, R, nullptr, 0, 3));  // mask.py:191-194
     ReshapeParams rs{a.labels.as<uint8_t>(), a.bbox.as<int>(), out, n, R, R, h, w};  // mask.py:196-202
     {

@@ -80,9 +80,7 @@ class ShardedPipeline:
         # ---- sliced stages: no communication
         if n_r:
             e.L.check(lib.lm_preprocess_dev(e.h, vol_shard.data_ptr(), 0, n_r, h, w, oh, ow, bbox.data_ptr(), xf.data_ptr(), None, None), "lm_preprocess_dev")
-            for b0 in range(0, n_r, self.batch_size):
-                b = min(self.batch_size, n_r - b0)
-                e.L.check(lib.lm_forward_dev(e.h, self.slot, xf[b0:].data_ptr(), b, oh, ow, lab_loc[b0:].data_ptr(), None), "lm_forward_dev")
+            e.L.check(lib.lm_forward_batches_dev(e.h, self.slot, xf.data_ptr(), n_r, oh, ow, self.batch_size, lab_loc.data_ptr()), "lm_forward_batches_dev")
         e.sync()
         # ---- exchange #1: 256^2 label shards -> whole label volume on every rank (RCCL all-gather, in place)
         if self.world > 1:
