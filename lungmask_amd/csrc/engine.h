@@ -87,11 +87,22 @@ struct NNWorkspace {
     }
 };
 
+// Grow-only pinned host buffer (D2H of the region table / boundary records at PCIe speed instead of through a bounce buffer).
+struct HostBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
 struct PostWorkspace {
+    HostBuf h_area, h_labval, h_recs;
     DevBuf parent, ids, rank, bgparent, blockcnt, area, labval, recs, lut, mapped, bg, out, scalars;
     void release() {
         parent.release(); ids.release(); rank.release(); bgparent.release(); blockcnt.release(); area.release(); labval.release();
         recs.release(); lut.release(); mapped.release(); bg.release(); out.release(); scalars.release();
+        h_area.release(); h_labval.release(); h_recs.release();
     }
 };
 

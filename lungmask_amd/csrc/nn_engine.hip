@@ -38,6 +38,26 @@ void DevBuf::release() {
     cap = 0;
 }
 
+int HostBuf::reserve(size_t bytes) {
+    if (bytes <= cap) return LM_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = bytes + bytes / 2;
+    hipError_t err = hipHostMalloc(&p, want, 0);
+    if (err != hipSuccess) {
+        set_error("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(err));
+        return LM_ERR_ALLOC;
+    }
+    cap = want;
+    return LM_OK;
+}
+void HostBuf::release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
 void Model::release() {
     for (void* a : allocs) (void)hipFree(a);
     allocs.clear();

@@ -39,15 +39,15 @@ struct ProfScope {
 };
 
 // utils.py:303-342 on the region graph.  Returns lut[atom] = final label value (0 = removed).
-void replay_merge(int R, const std::vector<int>& area, const std::vector<uint8_t>& lv, const std::vector<BoundaryRec>& recs,
-                  const std::vector<int>& spare, int skip_below, std::vector<uint8_t>& lut, PostInfo& info) {
+void replay_merge(int R, const int* area, const uint8_t* lv, const BoundaryRec* recs, size_t nrecs, const std::vector<int>& spare,
+                  int skip_below, std::vector<uint8_t>& lut, PostInfo& info) {
     std::vector<int> order(R);
     std::iota(order.begin(), order.end(), 1);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return area[a] < area[b]; });  // :299
     unsigned maxsub[256];
     memset(maxsub, 0, sizeof maxsub);
     std::vector<uint8_t> lobemap(R + 1, 0);
-    std::vector<long long> cache_area(area.begin(), area.end());
+    std::vector<long long> cache_area(area, area + R + 1);
     for (int r : order) {  // :303-308
         const int mi = lv[r];
         if (cache_area[r] > (long long)maxsub[mi]) {
@@ -66,13 +66,13 @@ void replay_merge(int R, const std::vector<int>& area, const std::vector<uint8_t
     };
     // adjacency: atom -> records in which it appears as a neighbour
     std::vector<unsigned> adj_off(R + 2, 0);
-    for (const BoundaryRec& rc : recs)
-        for (int k = 0; k < 6 && rc.nb[k]; ++k) adj_off[rc.nb[k] + 1]++;
+    for (size_t j = 0; j < nrecs; ++j)
+        for (int k = 0; k < 6 && recs[j].nb[k]; ++k) adj_off[recs[j].nb[k] + 1]++;
     for (int i = 1; i <= R + 1; ++i) adj_off[i] += adj_off[i - 1];
     std::vector<unsigned> adj(adj_off[R + 1]);
     {
         std::vector<unsigned> fill(adj_off.begin(), adj_off.end() - 1);
-        for (size_t j = 0; j < recs.size(); ++j)
+        for (size_t j = 0; j < nrecs; ++j)
             for (int k = 0; k < 6 && recs[j].nb[k]; ++k) adj[fill[recs[j].nb[k]]++] = (unsigned)j;
     }
     // current id of every atom: union-find + member lists
@@ -85,7 +85,7 @@ void replay_merge(int R, const std::vector<int>& area, const std::vector<uint8_t
         }
         return a;
     };
-    std::vector<int> stamp(recs.size(), 0), counts(R + 1, 0), touched;
+    std::vector<int> stamp(nrecs, 0), counts(R + 1, 0), touched;
     for (int r : order) {  // :310-339
         const int mi = lv[r];
         if (!((cache_area[r] < (long long)maxsub[mi] || spare_label[mi]) && cache_area[r] >= skip_below)) continue;
@@ -204,16 +204,19 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
             cap = nrec;  // rare: grow and redo
         }
         info.boundary_records = nrec;
-        std::vector<int> area((size_t)R + 1);
-        std::vector<uint8_t> lv((size_t)R + 1);
-        std::vector<BoundaryRec> recs(nrec);
-        LM_HIP(hipMemcpyAsync(area.data(), ws.area.p, ((size_t)R + 1) * 4, hipMemcpyDeviceToHost, s));
-        LM_HIP(hipMemcpyAsync(lv.data(), ws.labval.p, (size_t)R + 1, hipMemcpyDeviceToHost, s));
-        if (nrec) LM_HIP(hipMemcpyAsync(recs.data(), ws.recs.p, (size_t)nrec * sizeof(BoundaryRec), hipMemcpyDeviceToHost, s));
+        LM_TRY(ws.h_area.reserve(((size_t)R + 1) * 4));
+        LM_TRY(ws.h_labval.reserve((size_t)R + 1));
+        LM_TRY(ws.h_recs.reserve(std::max<size_t>((size_t)nrec * sizeof(BoundaryRec), 64)));
+        const int* area = ws.h_area.as<int>();
+        const uint8_t* lv = ws.h_labval.as<uint8_t>();
+        const BoundaryRec* recs = ws.h_recs.as<BoundaryRec>();
+        LM_HIP(hipMemcpyAsync(ws.h_area.p, ws.area.p, ((size_t)R + 1) * 4, hipMemcpyDeviceToHost, s));
+        LM_HIP(hipMemcpyAsync(ws.h_labval.p, ws.labval.p, (size_t)R + 1, hipMemcpyDeviceToHost, s));
+        if (nrec) LM_HIP(hipMemcpyAsync(ws.h_recs.p, ws.recs.p, (size_t)nrec * sizeof(BoundaryRec), hipMemcpyDeviceToHost, s));
         LM_HIP(hipStreamSynchronize(s));
         // ---- (4) the sequential merge on the region graph                                  utils.py:299-342
         const auto t0 = std::chrono::steady_clock::now();
-        replay_merge(R, area, lv, recs, spare, skip_below, lut, info);
+        replay_merge(R, area, lv, recs, nrec, spare, skip_below, lut, info);
         info.host_replay_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     LM_TRY(ws.lut.reserve(lut.size()));

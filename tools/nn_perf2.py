@@ -4,15 +4,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from lungmask_amd import _native as nat
 from oracle import unet_oracle as uo
-B = 20; iters = 8
+B = 20; iters = 12
 sd = uo.synthetic_state_dict(3)
-engs = [nat.Engine(0) for _ in range(2)]
+engs = [nat.Engine(0) for _ in range(3)]
 xs, labs = [], []
 for e in engs:
-    e.load_state_dict(0, sd); e.set_precision("split_f16")
+    e.load_state_dict(0, sd); e.set_precision("split_f16"); e.set_streams(1)
     xs.append(e.to_device(np.random.default_rng(0).random((B, 256, 256), dtype=np.float32)))
     labs.append(e.empty((B, 256, 256), np.uint8))
-for n_eng in (1, 2, 1, 2):
+for n_eng in (1, 2, 3, 1, 2, 3):
     for e, x, l in zip(engs, xs, labs): e.forward_dev(0, x, l)
     for e in engs: e.sync()
     t = time.time()
