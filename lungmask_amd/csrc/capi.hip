@@ -5,6 +5,10 @@
 
 using namespace lm;
 
+// every entry point that launches work first makes the engine's device current (callers such as
+// torch.distributed workers may have switched devices on this thread)
+#define LM_DEVICE(e) LM_HIP(hipSetDevice((e)->device))
+
 extern "C" {
 
 const char* lm_last_error(void) { return get_error(); }
@@ -125,11 +129,13 @@ int lm_set_streams(lm_engine* e, int n) {
 
 int lm_forward_batches_dev(lm_engine* e, int slot, const float* x_dev, int n, int h, int w, int batch_size, uint8_t* labels_dev) {
     if (!e || !x_dev || !labels_dev || n < 0) return LM_ERR_INVALID;
+    LM_DEVICE(e);
     return forward_batches(e, slot, x_dev, n, h, w, batch_size, labels_dev);
 }
 
 int lm_forward_dev(lm_engine* e, int slot, const float* x_dev, int b, int h, int w, uint8_t* labels_dev, float* logp_dev) {
     if (!e || !x_dev) return LM_ERR_INVALID;
+    LM_DEVICE(e);
     return forward(e, slot, x_dev, b, h, w, labels_dev, logp_dev);
 }
 
@@ -143,6 +149,7 @@ int lm_preprocess_dev(lm_engine* e, const void* vol_dev, int dtype, int n, int h
         set_error("lm_preprocess_dev: unsupported dtype code %d (integer HU volumes only)", dtype);
         return LM_ERR_INVALID;
     }
+    LM_DEVICE(e);
     BodyMaskParams bp{vol_dev, dtype, n, h, w, bbox_dev, bmask_dev};
     const double vox = (double)n * h * w;
     const int esz = dtype == LM_I16 ? 2 : (dtype == LM_I32 ? 4 : 8);
@@ -172,6 +179,7 @@ int lm_reshape_mask_dev(lm_engine* e, const uint8_t* mask_dev, const int32_t* bb
         set_error("lm_reshape_mask_dev: bad arguments");
         return LM_ERR_INVALID;
     }
+    LM_DEVICE(e);
     ReshapeParams p{mask_dev, bbox_dev, out_dev, n, mh, mw, h, w};
     e->prof.begin(e->stream, e->prof.kind_id("reshape_mask"), 0, (double)n * ((double)mh * mw + (double)h * w));
     hipError_t err = launch_reshape_mask(p, e->stream);
@@ -188,6 +196,7 @@ int lm_postprocess_dev(lm_engine* e, uint8_t* lab_dev, int n, int h, int w, cons
         set_error("lm_postprocess_dev: bad arguments");
         return LM_ERR_INVALID;
     }
+    LM_DEVICE(e);
     return postprocess(e, lab_dev, n, h, w, spare, n_spare, skip_below);
 }
 
@@ -203,6 +212,7 @@ int lm_postprocess_info(lm_engine* e, int64_t info[5]) {
 
 int lm_fuse_dev(lm_engine* e, uint8_t* res_l_dev, const uint8_t* res_r_dev, size_t nvox, int* spare_out) {
     if (!e || !res_l_dev || !res_r_dev) return LM_ERR_INVALID;
+    LM_DEVICE(e);
     LM_TRY(e->post.scalars.reserve(4096));
     unsigned* mx_dev = e->post.scalars.as<unsigned>() + 2;
     hipError_t err = volume_max(res_l_dev, mx_dev, nvox, e->stream);
@@ -229,6 +239,7 @@ int lm_apply_dev(lm_engine* e, int slot, int fill_slot, const void* vol_dev, int
         set_error("lm_apply_dev: bad arguments");
         return LM_ERR_INVALID;
     }
+    LM_DEVICE(e);
     return apply_volume(e, slot, fill_slot, vol_dev, dtype, n, h, w, batch_size, volume_postprocessing, out_dev);
 }
 
@@ -243,6 +254,7 @@ int lm_apply_host(lm_engine* e, int slot, int fill_slot, const void* vol_host, i
         set_error("lm_apply_host: unsupported dtype code %d (integer HU volumes only)", dtype);
         return LM_ERR_INVALID;
     }
+    LM_DEVICE(e);
     const size_t nvox = (size_t)n * h * w;
     LM_TRY(e->app.vol.reserve(nvox * esz));
     LM_TRY(e->app.out.reserve(nvox));

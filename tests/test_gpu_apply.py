@@ -109,3 +109,30 @@ def test_real_weights_golden_counts_if_available(gpu_engine):
     if not wd or not os.path.exists(os.path.join(wd, "unet_r231-d5d2fc3d.pth")):
         pytest.skip("pretrained weights not available offline")
     pytest.skip("fixture DICOM not shipped; see INTEGRATION.md")
+
+
+def test_sharded_pipeline_world1_on_torch_cuda_tensors(gpu_engine):
+    """The multi-GPU pipeline's degenerate world_size=1 path on the GPU: torch.cuda tensors own the buffers, the
+    engine receives raw pointers (the N>1 collectives are covered by the gloo test in the CPU suite)."""
+    from lungmask_amd.pipeline import ShardedPipeline
+
+    sd = uo.synthetic_state_dict(3)
+    gpu_engine.load_state_dict(0, sd)
+    vol = po.phantom(25, 512, 512, seed=12)  # 25 slices, batch 20: two batches on two forward lanes, ragged tail
+    pipe = ShardedPipeline(gpu_engine, slot=0, batch_size=20, device="cuda:0")
+    out = pipe.apply_shard(torch.from_numpy(vol).to("cuda:0"), len(vol)).cpu().numpy()
+    assert np.array_equal(out, gpu_engine.apply(0, vol, batch_size=20))
+
+
+def test_apply_is_independent_of_batch_size_and_lanes(gpu_engine):
+    sd = uo.synthetic_state_dict(3)
+    gpu_engine.load_state_dict(0, sd)
+    vol = po.phantom(23, 512, 512, seed=30)
+    ref = gpu_engine.apply(0, vol, batch_size=20)
+    for bs in (1, 7, 23, 64):
+        assert np.array_equal(gpu_engine.apply(0, vol, batch_size=bs), ref), bs
+    gpu_engine.set_streams(1)
+    try:
+        assert np.array_equal(gpu_engine.apply(0, vol, batch_size=5), ref)
+    finally:
+        gpu_engine.set_streams(2)
