@@ -203,12 +203,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(ConvParamsH3 p) {
 // offsets (the bank swizzle depends on the halo COLUMN only, so tap shifts are plain byte offsets); both
 // fragment streams are bank-conflict free.  The 2x2 average pool is in-lane (two N-tiles) + one lane^1 exchange.
 namespace {
-template <int TAPS>
+// G16 = false: one slice, tile 16 rows x 32 cols.  G16 = true (16-pixel-wide levels): TWO slices per item, each
+// a 16x16 tile with its own halo; waves 0-3 work on the first slice, 4-7 on the second.
+template <int TAPS, bool G16>
 struct H3WSmem {
     static constexpr int HALO = (TAPS == 9) ? 1 : 0;
-    static constexpr int TWW = 32;
+    static constexpr int TWW = G16 ? 16 : 32;
+    static constexpr int NSL = G16 ? 2 : 1;
     static constexpr int PW = TWW + 2 * HALO, PH = TH + 2 * HALO;
-    static constexpr int A_ROWS = PH * PW;
+    static constexpr int SL_ROWS = PH * PW;  // halo pixels of one slice
+    static constexpr int A_ROWS = NSL * SL_ROWS;
+    static constexpr int NTSTEP = G16 ? 2 : 1;  // halo rows between the two N-tiles of a wave
     static constexpr int W_ROWS = TAPS * TN;
     static constexpr int A_PIECES = (A_ROWS * 4 + 63) / 64, W_PIECES = W_ROWS * 4 / 64;
     static constexpr int A_BYTES = A_PIECES * 1024, W_BYTES = W_PIECES * 1024;
@@ -229,8 +234,8 @@ __device__ __forceinline__ float4 as_float4(const lm_h16x8& v) {
         const int a_lo_ = a_off[DX] ^ 16;                                                     \
         LM_LDS_READ128(f[4], as + a_off[DX], (DY) * ROWB);                                    \
         LM_LDS_READ128(f[5], as + a_lo_, (DY) * ROWB);                                        \
-        LM_LDS_READ128(f[6], as + a_off[DX], ((DY) + 1) * ROWB);                              \
-        LM_LDS_READ128(f[7], as + a_lo_, ((DY) + 1) * ROWB);                                  \
+        LM_LDS_READ128(f[6], as + a_off[DX], ((DY) + NTSTEP) * ROWB);                         \
+        LM_LDS_READ128(f[7], as + a_lo_, ((DY) + NTSTEP) * ROWB);                             \
         LM_LDS_READ128(f[0], as + w_off, (3 * (DY) + (DX)) * (TN * 64));                      \
         LM_LDS_READ128(f[1], as + w_off, (3 * (DY) + (DX)) * (TN * 64) + 2048);               \
         LM_LDS_READ128(f[2], as + w_off_lo, (3 * (DY) + (DX)) * (TN * 64));                   \
@@ -250,10 +255,10 @@ __device__ __forceinline__ float4 as_float4(const lm_h16x8& v) {
         accc[1][1] = lm_mfma_f32_32x32x16_f16(f[3], f[6], accc[1][1]);                        \
     } while (0)
 
-template <int TAPS>
+template <int TAPS, bool G16>
 __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptiles, int n_items) {
-    using SM = H3WSmem<TAPS>;
-    constexpr int HALO = SM::HALO, PW = SM::PW, TWW = SM::TWW, NW = SM::NW, ROWB = PW * 64;
+    using SM = H3WSmem<TAPS, G16>;
+    constexpr int HALO = SM::HALO, PW = SM::PW, TWW = SM::TWW, NW = SM::NW, ROWB = PW * 64, NTSTEP = SM::NTSTEP;
     constexpr int PSTR = 272;                   // staged pixel stride of the epilogue: 256 B of split data + 16 B pad
     constexpr int STAGE_BYTES = NW * 32 * PSTR;  // one 32-pixel row per wave
     // The epilogue staging area reuses the DMA buffer of the last chunk when it fits (3x3: 75 KiB), else it is extra.
@@ -263,21 +268,25 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
 
     const int tid = threadIdx.x, lane = tid & 63, wave = lm_uniform(tid >> 6);
     const int li = lane & 31, kb = lane >> 5;
-    const int rp = wave;  // row pair of the 16x32 tile owned by this wave (both 32-cout M-tiles)
+    // wave -> pixels.  G32: rows 2w, 2w+1 of the tile, lane li = column.  G16: slice w>>2, rows 4(w&3)..+3 as two
+    // N-tiles of 2 rows x 16 cols (lane li = 16*row + column).
+    const int wsl = G16 ? (wave >> 2) : 0;                       // slice of the item this wave works on
+    const int wrow = G16 ? 4 * (wave & 3) + (li >> 4) : 2 * wave;  // first tile row of this lane (N-tile 0)
+    const int wcol = G16 ? (li & 15) : li;
 
     // ---- fragment byte offsets inside a buffer (item invariant)
     int a_off[TAPS == 9 ? 3 : 1];
 #pragma unroll
     for (int dx = 0; dx < (TAPS == 9 ? 3 : 1); ++dx) {
-        const int px = li + dx;
-        a_off[dx] = ((2 * rp) * PW + px) * 64 + ((2 * kb) ^ ((px >> 2) & 3)) * 16;
+        const int px = wcol + dx;
+        a_off[dx] = (wsl * SM::SL_ROWS + wrow * PW + px) * 64 + ((2 * kb) ^ ((px >> 2) & 3)) * 16;
     }
     const int w_off = SM::A_BYTES + li * 64 + ((2 * kb) ^ ((li >> 2) & 3)) * 16;  // second M-tile: +2048
     const int w_off_lo = w_off ^ 16;
 
     // ---- DMA lane geometry (item invariant): which halo pixel / weight row this lane feeds
     unsigned relA[SM::A_PER_WAVE];
-    int pyx[SM::A_PER_WAVE];  // py | px << 8, or -1 when the lane has nothing to do for that piece
+    int pyx[SM::A_PER_WAVE];  // py | px << 8 | slice << 16, or -1 when the lane has nothing to do for that piece
 #pragma unroll
     for (int j = 0; j < SM::A_PER_WAVE; ++j) {
         const int piece = wave + NW * j, idx = piece * 64 + lane;
@@ -285,10 +294,11 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
         relA[j] = 0;
         if (piece < SM::A_PIECES && idx < SM::A_ROWS * 4) {
             const int row = idx >> 2;
-            const int py = row / PW, px = row - py * PW;
+            const int sl = row / SM::SL_ROWS, rr = row - sl * SM::SL_ROWS;
+            const int py = rr / PW, px = rr - py * PW;
             const int ls = (idx & 3) ^ ((px >> 2) & 3);
-            relA[j] = (unsigned)((py * p.W + px) * p.in_cstride * 4 + (ls >> 1) * 32 + (ls & 1) * 16);
-            pyx[j] = py | (px << 8);
+            relA[j] = (unsigned)(((sl * p.H + py) * p.W + px) * p.in_cstride * 4 + (ls >> 1) * 32 + (ls & 1) * 16);
+            pyx[j] = py | (px << 8) | (sl << 16);
         }
     }
     unsigned relW0;
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
         pt /= tiles_x;
         const int tiles_y = (p.H + TH - 1) / TH;
         const int ty = pt % tiles_y;
-        b = pt / tiles_y;
+        b = (pt / tiles_y) * SM::NSL;  // first slice of the item
         y0 = ty * TH;
         x0 = tx * TWW;
         n0 = ct * TN;
@@ -323,8 +333,8 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
         bool inb[SM::A_PER_WAVE];
 #pragma unroll
         for (int j = 0; j < SM::A_PER_WAVE; ++j) {
-            const int gy = y0 + (pyx[j] & 0xff) - HALO, gx = x0 + (pyx[j] >> 8) - HALO;
-            inb[j] = pyx[j] >= 0 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            const int gy = y0 + (pyx[j] & 0xff) - HALO, gx = x0 + ((pyx[j] >> 8) & 0xff) - HALO;
+            inb[j] = pyx[j] >= 0 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && b + (pyx[j] >> 16) < p.B;
             if (pyx[j] >= 0 && !inb[j]) {
                 const uint4 z = {0u, 0u, 0u, 0u};
                 *reinterpret_cast<uint4*>(buf + ((wave + NW * j) * 64 + lane) * 16) = z;
@@ -404,13 +414,16 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
             // 256-byte pixel rows written 16 bytes per lane (the scattered form cost ~10 us per tile in the TA).
             __syncthreads();
             char* stage = (STAGE_EXTRA ? lds + 2 * SM::BUF_BYTES : lds + (par ^ 1) * SM::BUF_BYTES) + wave * (32 * PSTR);
-            const int yb = y0 + 2 * rp;
+            const int bs = b + wsl;                      // slice this wave writes
+            const int yb = y0 + (G16 ? 4 * (wave & 3) : 2 * wave);  // first image row of the wave's N-tile 0
             const int Hp = p.H >> 1, Wp = p.W >> 1;
-            char* prow = p.pool ? p.pool + ((((size_t)b * Hp + (yb >> 1)) * Wp + ((x0 + li) >> 1)) * p.pool_cstride + p.pool_coff) * 4 : nullptr;
             const char* ep = reinterpret_cast<const char*>(&epi[epar][0][0]);
-            float pl[8][4];  // row yb + row yb+1 (for the pool)
+            float pl[8][4];  // G32: row yb + row yb+1 (for the pool)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
+                // image row of this lane's pixel in N-tile nt, and whether the wave's 32 pixels of this N-tile exist
+                const int yl = G16 ? yb + 2 * nt + (li >> 4) : yb + nt;
+                const bool tile_ok = bs < p.B && (G16 ? yb + 2 * nt + 1 < p.H : yb + nt < p.H);
 #pragma unroll
                 for (int mg = 0; mg < 8; ++mg) {
                     const int mt = mg >> 2, g = mg & 3;
@@ -428,19 +441,33 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                         float t = fmaf(accc[mt][nt][4 * g + k], kLoInv, accm[mt][nt][4 * g + k]) + bb[k];
                         if (bn) t = fmaf(fmaxf(t, 0.f), ss[k], tt[k]);
                         v[k] = t;
-                        pl[mg][k] = nt == 0 ? t : pl[mg][k] + t;
+                        if (!G16) pl[mg][k] = nt == 0 ? t : pl[mg][k] + t;
                     }
                     uint2 ph, plo;
                     lm_split4(v[0], v[1], v[2], v[3], &ph, &plo);
                     char* d = stage + li * PSTR + (cl >> 3) * 32 + (cl & 7) * 2;
                     *reinterpret_cast<uint2_a*>(d) = ph;
                     *reinterpret_cast<uint2_a*>(d + 16) = plo;
+                    if (G16 && p.pool != nullptr) {  // both pool partners are in this N-tile: lane^16 (y+1) and lane^1 (x+1)
+                        float q[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float h = v[k] + __shfl_xor(v[k], 16);
+                            q[k] = 0.25f * (h + __shfl_xor(h, 1));
+                        }
+                        if (tile_ok && (li & 17) == 0) {
+                            const int cg = n0 + cl;
+                            char* prow = p.pool + ((((size_t)bs * Hp + (yl >> 1)) * Wp + (wcol >> 1)) * p.pool_cstride + p.pool_coff) * 4;
+                            split_store4(prow + (size_t)(cg >> 3) * 32, (cg & 7) * 2, q[0], q[1], q[2], q[3]);
+                        }
+                    }
                 }
-                // the wave's own 32 pixels x 256 B are now in LDS (same-wave LDS ops are ordered): stream them out
+                // the wave's own 32 pixels x 256 B are now in LDS (same-wave LDS ops are ordered): stream them out.
+                // G32: 32 consecutive pixels of one image row; G16 (W == 16): two consecutive 16-pixel rows = 32 consecutive pixels.
                 lm_wave_lds_fence();
-                const int y = yb + nt;
-                if (y < p.H) {
-                    char* orow = p.out + ((((size_t)b * p.H + y) * p.W + x0) * p.out_cstride + p.out_coff + n0) * 4;
+                if (tile_ok) {
+                    const int y_first = G16 ? yb + 2 * nt : yb + nt;
+                    char* orow = p.out + ((((size_t)bs * p.H + y_first) * p.W + x0) * p.out_cstride + p.out_coff + n0) * 4;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const int q = i * 64 + lane, px = q >> 4, part = q & 15;
@@ -450,7 +477,8 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                 }
                 lm_wave_lds_fence();  // the staging rows are rewritten by the next row
             }
-            if (p.pool != nullptr) {  // avg_pool2d(2): rows yb, yb+1 summed above; x+1 is lane^1
+            if (!G16 && p.pool != nullptr) {  // avg_pool2d(2): rows yb, yb+1 summed above; x+1 is lane^1
+                char* prow = p.pool + ((((size_t)bs * Hp + (yb >> 1)) * Wp + ((x0 + li) >> 1)) * p.pool_cstride + p.pool_coff) * 4;
 #pragma unroll
                 for (int mg = 0; mg < 8; ++mg) {
                     const int cg = n0 + 32 * (mg >> 2) + 8 * (mg & 3) + 4 * kb;
@@ -479,8 +507,9 @@ static hipError_t launch_conv_h3_t(const ConvParamsH3& p, hipStream_t stream) {
     ConvParamsH3 pd = p;
     pd.dbg = dbg;
     static const bool wide_ok = [] { const char* e = getenv("LM_H3_WIDE"); return !(e && e[0] == '0'); }();  // tuning knob
-    if (wide_ok && p.W % 32 == 0 && (size_t)p.H * p.W * p.in_cstride * 4 < 0x7fffffffull && (size_t)TAPS * p.Cout * p.Cin * 4 < 0x7fffffffull) {
-        const int n_ptiles = (p.W / 32) * ((p.H + TH - 1) / TH) * p.B;
+    const bool g16 = p.W == 16;
+    if (wide_ok && (p.W % 32 == 0 || g16) && (size_t)2 * p.H * p.W * p.in_cstride * 4 < 0x7fffffffull && (size_t)TAPS * p.Cout * p.Cin * 4 < 0x7fffffffull) {
+        const int n_ptiles = g16 ? ((p.H + TH - 1) / TH) * ((p.B + 1) / 2) : (p.W / 32) * ((p.H + TH - 1) / TH) * p.B;
         const int n_items = n_ptiles * (p.Cout / TN);
         static const int n_cu = [] {
 #ifdef LM_EMU_BUILD
@@ -492,7 +521,10 @@ static hipError_t launch_conv_h3_t(const ConvParamsH3& p, hipStream_t stream) {
 #endif
         }();
         const unsigned blocks = (unsigned)std::min(n_items, n_cu);
-        LM_LAUNCH((conv_igemm_h3p<TAPS>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items);
+        if (g16)
+            LM_LAUNCH((conv_igemm_h3p<TAPS, true>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items);
+        else
+            LM_LAUNCH((conv_igemm_h3p<TAPS, false>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items);
         return hipGetLastError();
     }
     const int tiles = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH);
