@@ -76,6 +76,15 @@ __device__ __forceinline__ lm_f32x16 lm_mfma_f32_32x32x2(float a, float b, lm_f3
 #endif
 }
 
+// Every LDS-DMA this wave has issued has landed (and every store has left).  Stated explicitly in front of the
+// barriers that publish DMA'd data: the compiler's own vmcnt(0) in __syncthreads() was found missing on one
+// control-flow path of one instantiation (a rare wrong tile on the GPU, never in the emulator).
+__device__ __forceinline__ void lm_dma_wait_all() {
+#ifndef LM_EMU_BUILD
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
 // 4-byte variant (global_load_lds_dword): 64 lanes fill 256 contiguous LDS bytes.
 __device__ __forceinline__ void lm_global_load_lds4(const void* gsrc, void* lds_wave_base) {
 #ifdef LM_EMU_BUILD

@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(ConvParamsH3 p) {
             const char* src = p.w + ((size_t)tap * p.Cout + n0 + n) * w_row_bytes + (size_t)((c0 >> 3) + (ls >> 1)) * 32 + (ls & 1) * 16;
             lm_global_load_lds16(src, Ws + piece * 1024);
         }
-        __syncthreads();  // (the compiler drains vmcnt for the LDS-DMA before the barrier)
+        lm_dma_wait_all();
+        __syncthreads();  // the DMA'd tile is complete for every wave
 #pragma unroll 1
         for (int tap = 0; tap < TAPS; ++tap) {
             const int dy = (TAPS == 9) ? tap / 3 : 0, dx = (TAPS == 9) ? tap - 3 * dy : 0;
@@ -386,6 +387,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
         int nb = 0, ny0 = 0, nx0 = 0, nn0 = 0;
         if (have_next) decode(nit, nb, ny0, nx0, nn0);
         for (int ci = 0; ci < nchunks; ++ci) {
+            lm_dma_wait_all();
             __syncthreads();  // chunk ci of this item has landed in buffer `par`; everyone is done with the other buffer
             if (!(p.dbg & 2)) {
                 if (ci + 1 < nchunks) issue(b, y0, x0, n0, (ci + 1) * KC, par ^ 1, false, epar);
@@ -412,6 +414,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
             // All waves are done with the buffer of the last chunk: it becomes the staging area that turns the
             // accumulator layout (lane = pixel, 8 bytes per 4 couts: 64 scattered lines per store) into full
             // 256-byte pixel rows written 16 bytes per lane (the scattered form cost ~10 us per tile in the TA).
+            lm_dma_wait_all();
             __syncthreads();
             char* stage = (STAGE_EXTRA ? lds + 2 * SM::BUF_BYTES : lds + (par ^ 1) * SM::BUF_BYTES) + wave * (32 * PSTR);
             const int bs = b + wsl;                      // slice this wave writes

@@ -36,13 +36,22 @@ def run_case(eng, sd, vol, batch):
     ref_lab, margin = oracle_forward(sd, x)
     lab = gpu_labels(eng, 0, x)
     bad = lab != ref_lab
-    assert not np.any(bad & (margin > 2 * TOL)), int(bad.sum())
+    assert not np.any(bad & (margin > 2 * TOL)), f"forward: {int(bad.sum())} label mismatches, some away from near-ties"
+    # the batched / two-lane forward inside lm_apply must give the same labels as one lm_forward_dev call
+    xd = eng.to_device(x[:, 0])
+    ld = eng.empty(lab.shape, np.uint8)
+    eng.L.check(eng.L.lib.lm_forward_batches_dev(eng.h, 0, xd.ptr, len(x), 256, 256, batch, ld.ptr))
+    eng.sync()
+    lab_b = ld.download()
+    assert np.array_equal(lab_b, lab), f"forward_batches differs from forward in {int((lab_b != lab).sum())} pixels"
     post = po.postprocessing(lab.copy())
+    gpost = eng.postprocess(lab)
+    assert np.array_equal(gpost, post), f"postprocess differs from the oracle in {int((gpost != post).sum())} voxels"
     expect = np.asarray([po.reshape_mask(post[i], boxes[i], vol.shape[1:]) for i in range(len(post))], dtype=np.uint8)
-    assert np.array_equal(out, expect), int((out != expect).sum())
+    assert np.array_equal(out, expect), f"apply differs from oracle(pre)+engine labels+oracle(post,un-crop) in {int((out != expect).sum())} voxels"
     if not bad.any():
-        pure = po.inference(vol, lambda xb: oracle_forward(sd, xb)[0], batch_size=batch)
-        assert np.array_equal(out, pure)
+        pure = po.inference(vol, lambda xb: oracle_forward(sd, xb)[0], batch_size=len(vol))
+        assert np.array_equal(out, pure), "apply differs from the pure oracle pipeline"
     return int(bad.sum())
 
 
