@@ -60,3 +60,38 @@ def test_forward_batch20_vs_oracle(gpu_engine, precision):
     # determinism: same input twice -> identical bytes
     lab2, logp2 = gpu_engine.forward(0, x)
     assert np.array_equal(lab, lab2) and np.array_equal(logp, logp2)
+
+
+def test_forward_repeatability_stress(gpu_engine):
+    """Race screen: the same input through the batched two-lane forward 60 times (ragged last batch, odd slice count
+    on the 16x16 level) must give identical bytes every time, and identical to a single-lane run."""
+    sd = uo.synthetic_state_dict(3)
+    gpu_engine.load_state_dict(0, sd)
+    rng = np.random.default_rng(17)
+    n = 45
+    x = gpu_engine.to_device(rng.random((n, 256, 256), dtype=np.float32))
+    lab = gpu_engine.empty((n, 256, 256), np.uint8)
+    lib = gpu_engine.L.lib
+
+    def run(batch):
+        gpu_engine.L.check(lib.lm_forward_batches_dev(gpu_engine.h, 0, x.ptr, n, 256, 256, batch, lab.ptr))
+        gpu_engine.sync()
+        return lab.download()
+
+    gpu_engine.set_streams(1)
+    ref = run(20)
+    gpu_engine.set_streams(2)
+    for it in range(60):
+        got = run(20 if it % 3 else 7)
+        assert np.array_equal(got, ref), f"iteration {it}: {int((got != ref).sum())} label bytes differ"
+    # log-probabilities of one batch, bit for bit
+    xs = gpu_engine.to_device(rng.random((5, 256, 256), dtype=np.float32))
+    lp = gpu_engine.empty((5, 3, 256, 256), np.float32)
+    l5 = gpu_engine.empty((5, 256, 256), np.uint8)
+    gpu_engine.forward_dev(0, xs, l5, lp)
+    gpu_engine.sync()
+    first = lp.download()
+    for it in range(40):
+        gpu_engine.forward_dev(0, xs, l5, lp)
+        gpu_engine.sync()
+        assert np.array_equal(lp.download(), first), f"iteration {it}"
