@@ -86,10 +86,10 @@ int lm_forward_dev(lm_engine* e, int slot, const float* x_dev, int b, int h, int
 
 /* ---- pre-processing (utils.py:32-111 preprocess / simple_bodymask / crop_and_resize,
  *      mask.py:166-168 clip + (x+1024)/1624) -------------------------------------- */
-/* vol_dev: [n][h][w] of `dtype` (LM_I16, LM_I32 or LM_I64).  Outputs (all dev):
+/* vol_dev: [n][h][w] of `dtype` (LM_I16, LM_I32, LM_I64, LM_F32 or LM_F64).  Outputs (all dev):
  *   bbox_dev   int32 [n][4]  body bounding box (r0,c0,r1,c1), utils.py:102-106
  *   x_f32_dev  f32 [n][oh][ow] normalised network input        (or NULL)
- *   x_i16_dev  i16 [n][oh][ow] == utils.preprocess()[0]        (or NULL)
+ *   x_i16_dev  i16 [n][oh][ow] == utils.preprocess()[0]        (or NULL; integer volumes only)
  *   bmask_dev  u8  [n][h][w]   == utils.simple_bodymask(slice) (or NULL; test seam) */
 int lm_preprocess_dev(lm_engine* e, const void* vol_dev, int dtype, int n, int h, int w, int oh, int ow,
                       int32_t* bbox_dev, float* x_f32_dev, int16_t* x_i16_dev, uint8_t* bmask_dev);
@@ -114,7 +114,7 @@ int lm_fuse_dev(lm_engine* e, uint8_t* res_l_dev, const uint8_t* res_r_dev, size
 
 /* ---- the whole hot path: LMInferer.apply on a numpy volume (mask.py:212-232) ---------- */
 /* slot: model; fill_slot: fill model for the fused LTRCLobes_R231 mode or -1.
- * vol: [n][h][w] of `dtype` (LM_I16/LM_I32/LM_I64); out: u8 [n][h][w].
+ * vol: [n][h][w] of `dtype` (LM_I16/LM_I32/LM_I64/LM_F32/LM_F64); out: u8 [n][h][w].
  * batch_size, volume_postprocessing: the LMInferer constructor arguments (mask.py:72-82).
  * _dev: both buffers already in HBM, nothing leaves the device.  _host: does the H2D / D2H. */
 int lm_apply_dev(lm_engine* e, int slot, int fill_slot, const void* vol_dev, int dtype, int n, int h, int w,

@@ -1,0 +1,115 @@
+"""`python -m lungmask_amd INPUT OUTPUT [...]` -- the reference's command line (lungmask/__main__.py:20-144)
+on the MI355X engine.  Same flags; thin by design (all I/O, off the hot path):
+
+* `.npy` / `.npz` volumes are read and written without any imaging dependency;
+* every other format goes through SimpleITK exactly like the reference (imported lazily; this image does not ship
+  it), including the DICOM tag carry-over of `--removemetadata`'s complement;
+* `--cpu` is accepted and refused: there is no CPU path in this engine.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+from .logger import logger
+from .mask import LMInferer
+
+VERSION = "0.2.20+mi355x"
+
+# utils.py:17-30
+DICOM_METADATA_TO_KEEP = ("0008|0020", "0008|0030", "0008|0050", "0008|0090", "0008|1030", "0010|0010", "0010|0020",
+                          "0010|0030", "0010|0040", "0018|5100", "0020|000d", "0020|0010")
+
+
+def path(string):  # __main__.py:13-17
+    if os.path.exists(string):
+        return string
+    sys.exit(f"File not found: {string}")
+
+
+def build_parser():
+    p = argparse.ArgumentParser(prog="lungmask_amd", formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument("input", metavar="input", type=path, help="Path to the input image, can be a folder for dicoms")
+    p.add_argument("output", metavar="output", type=str, help="Filepath for output lungmask")
+    p.add_argument("--modelname", help="spcifies the trained model, Default: R231", type=str,
+                   choices=["R231", "LTRCLobes", "LTRCLobes_R231", "R231CovidWeb"], default="R231")
+    p.add_argument("--modelpath", help="spcifies the path to the trained model", default=None)
+    p.add_argument("--cpu", help="Force using the CPU (not available in this engine)", action="store_true")
+    p.add_argument("--nopostprocess", help="Deactivates postprocessing (removal of unconnected components and hole filling)", action="store_true")
+    p.add_argument("--batchsize", type=int, help="Number of slices processed simultaneously.", default=20)
+    p.add_argument("--noprogress", action="store_true", help="If set, no tqdm progress bar will be shown")
+    p.add_argument("--version", help="Shows the current version of lungmask", action="version", version=VERSION)
+    p.add_argument("--removemetadata", action="store_true", help="Do not keep study/patient related metadata of the input, if any.")
+    return p
+
+
+def _load(path_, keepmetadata):
+    ext = os.path.splitext(path_)[1].lower()
+    if ext == ".npy":
+        return np.load(path_), None
+    if ext == ".npz":
+        z = np.load(path_)
+        return z[z.files[0]], None
+    import SimpleITK as sitk  # utils.load_input_image (utils.py:233-269)
+
+    if os.path.isfile(path_):
+        reader = sitk.ImageFileReader()
+        reader.SetFileName(path_)
+        if keepmetadata:
+            reader.LoadPrivateTagsOn()
+        img = reader.Execute()
+    else:
+        ids = sitk.ImageSeriesReader.GetGDCMSeriesIDs(path_)
+        if not ids:
+            sys.exit("No dicoms found!")
+        best = max(ids, key=lambda s: len(sitk.ImageSeriesReader.GetGDCMSeriesFileNames(path_, s)))
+        reader = sitk.ImageSeriesReader()
+        reader.SetFileNames(sitk.ImageSeriesReader.GetGDCMSeriesFileNames(path_, best))
+        reader.MetaDataDictionaryArrayUpdateOn()
+        img = reader.Execute()
+    return img, img
+
+
+def main(argv=None):
+    args = build_parser().parse_args(sys.argv[1:] if argv is None else argv)
+    keepmetadata = not args.removemetadata
+    logger.info("Load model")
+    image, ref_img = _load(args.input, keepmetadata)
+    logger.info("Infer lungmask")
+    if args.modelname == "LTRCLobes_R231":
+        assert args.modelpath is None, "Modelpath can not be specified for LTRCLobes_R231 mode"
+        inferer = LMInferer(modelname="LTRCLobes", force_cpu=args.cpu, fillmodel="R231", batch_size=args.batchsize,
+                            volume_postprocessing=not args.nopostprocess, tqdm_disable=args.noprogress)
+    else:
+        inferer = LMInferer(modelname=args.modelname, modelpath=args.modelpath, force_cpu=args.cpu, batch_size=args.batchsize,
+                            volume_postprocessing=not args.nopostprocess, tqdm_disable=args.noprogress)
+    result = inferer.apply(image)
+    logger.info(f"Save result to: {args.output}")
+    ext = os.path.splitext(args.output)[1].lower()
+    if ref_img is None or ext in (".npy", ".npz"):
+        if ext == ".npz":
+            np.savez_compressed(args.output, mask=result)
+        else:
+            np.save(args.output, result)
+        return 0
+    import SimpleITK as sitk
+
+    out = sitk.GetImageFromArray(result)
+    out.CopyInformation(ref_img)
+    writer = sitk.ImageFileWriter()
+    writer.SetFileName(args.output)
+    if keepmetadata:  # __main__.py:125-141
+        writer.SetKeepOriginalImageUID(True)
+        for key in ref_img.GetMetaDataKeys():
+            if key in DICOM_METADATA_TO_KEEP:
+                out.SetMetaData(key, ref_img.GetMetaData(key))
+        out.SetMetaData("0008|103e", "Created with lungmask")
+        out.SetMetaData("0028|1050", "1")
+        out.SetMetaData("0028|1051", "2")
+    writer.Execute(out)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -241,11 +241,11 @@ class Engine:
         vd = self.to_device(vol)
         bb = self.empty((n, 4), np.int32)
         xf = self.empty((n, resolution[0], resolution[1]), np.float32)
-        xi = self.empty((n, resolution[0], resolution[1]), np.int16)
+        xi = self.empty((n, resolution[0], resolution[1]), np.int16) if vol.dtype.kind == "i" else None
         bm = self.empty((n, h, w), np.uint8) if want_bmask else None
         self.preprocess_dev(vd, bb, xf, xi, bm, resolution)
         self.sync()
-        out = xi.download(), xf.download(), bb.download(), (bm.download() if bm else None)
+        out = (xi.download() if xi else None), xf.download(), bb.download(), (bm.download() if bm else None)
         for d in (vd, bb, xf, xi, bm):
             if d is not None:
                 d.free()

@@ -145,14 +145,18 @@ int lm_preprocess_dev(lm_engine* e, const void* vol_dev, int dtype, int n, int h
         set_error("lm_preprocess_dev: bad arguments");
         return LM_ERR_INVALID;
     }
-    if (dtype != LM_I16 && dtype != LM_I32 && dtype != LM_I64) {
-        set_error("lm_preprocess_dev: unsupported dtype code %d (integer HU volumes only)", dtype);
+    if (dtype != LM_I16 && dtype != LM_I32 && dtype != LM_I64 && dtype != LM_F32 && dtype != LM_F64) {
+        set_error("lm_preprocess_dev: unsupported dtype code %d", dtype);
+        return LM_ERR_INVALID;
+    }
+    if (x_i16_dev && (dtype == LM_F32 || dtype == LM_F64)) {
+        set_error("lm_preprocess_dev: the int16 resample output only exists for integer volumes");
         return LM_ERR_INVALID;
     }
     LM_DEVICE(e);
     BodyMaskParams bp{vol_dev, dtype, n, h, w, bbox_dev, bmask_dev};
     const double vox = (double)n * h * w;
-    const int esz = dtype == LM_I16 ? 2 : (dtype == LM_I32 ? 4 : 8);
+    const int esz = dtype == LM_I16 ? 2 : ((dtype == LM_I32 || dtype == LM_F32) ? 4 : 8);
     e->prof.begin(e->stream, e->prof.kind_id("bodymask_bbox"), 0, (double)n * 128 * 128 * esz);
     hipError_t err = launch_bodymask_bbox(bp, e->stream);
     e->prof.end(e->stream);
@@ -249,9 +253,9 @@ int lm_apply_host(lm_engine* e, int slot, int fill_slot, const void* vol_host, i
         set_error("lm_apply_host: bad arguments");
         return LM_ERR_INVALID;
     }
-    const int esz = dtype == LM_I16 ? 2 : (dtype == LM_I32 ? 4 : (dtype == LM_I64 ? 8 : 0));
+    const int esz = dtype == LM_I16 ? 2 : ((dtype == LM_I32 || dtype == LM_F32) ? 4 : ((dtype == LM_I64 || dtype == LM_F64) ? 8 : 0));
     if (!esz) {
-        set_error("lm_apply_host: unsupported dtype code %d (integer HU volumes only)", dtype);
+        set_error("lm_apply_host: unsupported dtype code %d", dtype);
         return LM_ERR_INVALID;
     }
     LM_DEVICE(e);

@@ -119,9 +119,6 @@ __device__ __forceinline__ void lm_split4(float v0, float v1, float v2, float v3
 // 16-byte LDS reads that the compiler's waitcnt pass cannot see (so it does not drain an in-flight LDS-DMA
 // in front of them), with an explicit counted wait that names every destination register.
 #ifdef LM_EMU_BUILD
-#define LM_KEEP_ALIVE2(a, b) \
-    do {                     \
-    } while (0)
 #define LM_OPAQUE3(a, b, c) \
     do {                    \
     } while (0)
@@ -136,7 +133,6 @@ __device__ __forceinline__ void lm_split4(float v0, float v1, float v2, float v3
     do {                                        \
     } while (0)
 #else
-#define LM_KEEP_ALIVE2(a, b) asm volatile("" ::"v"(a), "v"(b))
 #define LM_OPAQUE3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
 #define LM_LDS_WAIT6(N, a, b, c, d, e, f)                                                                         \
     do {                                                                                                          \

@@ -66,7 +66,6 @@ struct ConvParamsH3 {
     int pool_cstride, pool_coff;
     const char* zeros;  // >= 16 zero bytes in device memory (source of out-of-image halo pixels)
     int B, H, W, Cin, Cout;
-    int dbg;  // tuning ablations (LM_H3_DBG): bit0 = DMA only the first chunk, bit1 = LDS fragment reads only for tap 0
 };
 hipError_t launch_conv3x3_h3(const ConvParamsH3& p, hipStream_t stream);
 hipError_t launch_conv1x1_h3(const ConvParamsH3& p, hipStream_t stream);

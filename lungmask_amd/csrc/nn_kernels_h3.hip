@@ -389,10 +389,8 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
         for (int ci = 0; ci < nchunks; ++ci) {
             lm_dma_wait_all();
             __syncthreads();  // chunk ci of this item has landed in buffer `par`; everyone is done with the other buffer
-            if (!(p.dbg & 2)) {
-                if (ci + 1 < nchunks) issue(b, y0, x0, n0, (ci + 1) * KC, par ^ 1, false, epar);
-                else if (have_next) issue(nb, ny0, nx0, nn0, 0, par ^ 1, true, epar ^ 1);
-            }
+            if (ci + 1 < nchunks) issue(b, y0, x0, n0, (ci + 1) * KC, par ^ 1, false, epar);
+            else if (have_next) issue(nb, ny0, nx0, nn0, 0, par ^ 1, true, epar ^ 1);
             const char* as = lds + par * SM::BUF_BYTES;
             lm_h16x8 f[8];  // whi0 whi1 wlo0 wlo1 a0hi a0lo a1hi a1lo
             if (TAPS == 9) {
@@ -405,12 +403,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
             par ^= 1;
         }
         // ---- epilogue of this item (the first chunk of the next item is already in flight)
-        if (p.dbg & 1) {  // ablation: keep the accumulators alive, skip the epilogue
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) LM_KEEP_ALIVE2(accm[i][j], accc[i][j]);
-        } else {
+        {
             // All waves are done with the buffer of the last chunk: it becomes the staging area that turns the
             // accumulator layout (lane = pixel, 8 bytes per 4 couts: 64 scattered lines per store) into full
             // 256-byte pixel rows written 16 bytes per lane (the scattered form cost ~10 us per tile in the TA).
@@ -506,10 +499,9 @@ template <int TAPS>
 static hipError_t launch_conv_h3_t(const ConvParamsH3& p, hipStream_t stream) {
     if (p.Cin % KC != 0 || p.Cout % TN != 0 || (p.in_cstride & 7) || (p.in_coff & 7) || (p.out_cstride & 7) || (p.out_coff & 7)) return hipErrorInvalidValue;
     if (p.pool != nullptr && (((p.H | p.W) & 1) || (p.pool_cstride & 7) || (p.pool_coff & 7))) return hipErrorInvalidValue;
-    static const int dbg = [] { const char* e = getenv("LM_H3_DBG"); return e ? atoi(e) : 0; }();
-    ConvParamsH3 pd = p;
-    pd.dbg = dbg;
-    static const bool wide_ok = [] { const char* e = getenv("LM_H3_WIDE"); return !(e && e[0] == '0'); }();  // tuning knob
+    const ConvParamsH3& pd = p;
+    // LM_H3_FALLBACK=1 forces the simple 4-wave kernel everywhere (it normally only serves odd widths): test hook
+    static const bool wide_ok = [] { const char* e = getenv("LM_H3_FALLBACK"); return !(e && e[0] == '1'); }();
     const bool g16 = p.W == 16;
     if (wide_ok && (p.W % 32 == 0 || g16) && (size_t)2 * p.H * p.W * p.in_cstride * 4 < 0x7fffffffull && (size_t)TAPS * p.Cout * p.Cin * 4 < 0x7fffffffull) {
         const int n_ptiles = g16 ? ((p.H + TH - 1) / TH) * ((p.B + 1) / 2) : (p.W / 32) * ((p.H + TH - 1) / TH) * p.B;

@@ -272,7 +272,7 @@ int inference(lm_engine* e, int slot, const void* vol, int dtype, int n, int h, 
     LM_TRY(a.labels.reserve((size_t)n * R * R));
     if (!have_pre) {  // mask.py:166-168
         BodyMaskParams bp{vol, dtype, n, h, w, a.bbox.as<int>(), nullptr};
-        const int esz = dtype == LM_I16 ? 2 : (dtype == LM_I32 ? 4 : 8);
+        const int esz = dtype == LM_I16 ? 2 : ((dtype == LM_I32 || dtype == LM_F32) ? 4 : 8);
         {
             ProfScope ps(e, "bodymask_bbox", (double)n * 128 * 128 * esz);
             LM_K(launch_bodymask_bbox(bp, e->stream));
@@ -299,8 +299,8 @@ int apply_volume(lm_engine* e, int slot, int fill_slot, const void* vol, int dty
                  uint8_t* out) {
     if (n <= 0) return LM_OK;
     if (batch <= 0) batch = 20;
-    if (dtype != LM_I16 && dtype != LM_I32 && dtype != LM_I64) {
-        set_error("lm_apply: unsupported dtype code %d (integer HU volumes only)", dtype);
+    if (dtype != LM_I16 && dtype != LM_I32 && dtype != LM_I64 && dtype != LM_F32 && dtype != LM_F64) {
+        set_error("lm_apply: unsupported dtype code %d", dtype);
         return LM_ERR_INVALID;
     }
     LM_TRY(inference(e, slot, vol, dtype, n, h, w, batch, vol_post, false, out));

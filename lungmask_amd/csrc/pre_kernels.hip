@@ -323,12 +323,21 @@ __global__ __launch_bounds__(256) void resample_norm_kernel(ResampleParams p) {
             acc += (at(sr1, sc1) * wr1) * wc1;
             v = acc;
         }
-        // integer output dtype: round half away from zero, then truncate (scipy ni_interpolation)
-        const double rv = v > 0.0 ? v + 0.5 : v - 0.5;
-        const int16_t q = (int16_t)(int)rv;
-        if (p.out_i16) p.out_i16[idx] = q;
-        // mask.py:167-168: clip at 600 (no-op here), (x + 1024) / 1624 in float64 -> float32 (mask.py:178-181)
-        if (p.out_f32) p.out_f32[idx] = (float)((double)((int)q + 1024) / 1624.0);
+        if (sizeof(T) == 4 && (T)0.5 != (T)0) {
+            // float32 volume: zoom output is float32 (double result rounded once), then float32 arithmetic in numpy
+            const float vf = (float)v;
+            if (p.out_f32) p.out_f32[idx] = (vf + 1024.0f) / 1624.0f;
+        } else if ((T)0.5 != (T)0) {
+            // float64 volume: everything in float64, one final cast (mask.py:178-181)
+            if (p.out_f32) p.out_f32[idx] = (float)((v + 1024.0) / 1624.0);
+        } else {
+            // integer output dtype: round half away from zero, then truncate (scipy ni_interpolation)
+            const double rv = v > 0.0 ? v + 0.5 : v - 0.5;
+            const int16_t q = (int16_t)(int)rv;
+            if (p.out_i16) p.out_i16[idx] = q;
+            // mask.py:167-168: clip at 600 (no-op here), (x + 1024) / 1624 in float64 -> float32 (mask.py:178-181)
+            if (p.out_f32) p.out_f32[idx] = (float)((double)((int)q + 1024) / 1624.0);
+        }
     }
 }
 
@@ -358,6 +367,8 @@ hipError_t launch_bodymask_bbox(const BodyMaskParams& p, hipStream_t stream) {
         case LM_I16: LM_LAUNCH((bodymask_bbox_kernel<int16_t>), dim3((unsigned)p.N), dim3(128), 0, stream, p); break;
         case LM_I32: LM_LAUNCH((bodymask_bbox_kernel<int32_t>), dim3((unsigned)p.N), dim3(128), 0, stream, p); break;
         case LM_I64: LM_LAUNCH((bodymask_bbox_kernel<int64_t>), dim3((unsigned)p.N), dim3(128), 0, stream, p); break;
+        case LM_F32: LM_LAUNCH((bodymask_bbox_kernel<float>), dim3((unsigned)p.N), dim3(128), 0, stream, p); break;
+        case LM_F64: LM_LAUNCH((bodymask_bbox_kernel<double>), dim3((unsigned)p.N), dim3(128), 0, stream, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -371,6 +382,8 @@ hipError_t launch_resample_norm(const ResampleParams& p, hipStream_t stream) {
         case LM_I16: LM_LAUNCH((resample_norm_kernel<int16_t>), dim3(blocks), dim3(256), 0, stream, p); break;
         case LM_I32: LM_LAUNCH((resample_norm_kernel<int32_t>), dim3(blocks), dim3(256), 0, stream, p); break;
         case LM_I64: LM_LAUNCH((resample_norm_kernel<int64_t>), dim3(blocks), dim3(256), 0, stream, p); break;
+        case LM_F32: LM_LAUNCH((resample_norm_kernel<float>), dim3(blocks), dim3(256), 0, stream, p); break;
+        case LM_F64: LM_LAUNCH((resample_norm_kernel<double>), dim3(blocks), dim3(256), 0, stream, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -97,12 +97,11 @@ class LMInferer:
             if curr_orient != "LPS":
                 image = sitk.DICOMOrient(image, "LPS")
             inimg_raw = sitk.GetArrayFromImage(image)
-        if inimg_raw.dtype.kind == "f" or inimg_raw.dtype not in _native.LM_DTYPES:
-            # integer HU volumes are what CT readers produce; floats are rounded the way CT data arrives
-            if inimg_raw.dtype.kind in "iu":
-                inimg_raw = inimg_raw.astype(np.int32)
+        if inimg_raw.dtype not in (np.int16, np.int32, np.int64, np.float32, np.float64):
+            if inimg_raw.dtype.kind == "i" or inimg_raw.dtype == np.uint8:
+                inimg_raw = inimg_raw.astype(np.int32)  # value preserving; np.clip(-1024, 600) then behaves as for int32
             else:
-                raise TypeError(f"lungmask_amd: unsupported volume dtype {inimg_raw.dtype} (integer HU expected)")
+                raise TypeError(f"lungmask_amd: unsupported volume dtype {inimg_raw.dtype}")
         if self.fillmodel is not None:
             logger.info(f"Apply: {self.modelname}")
             logger.info(f"Apply: {self.fillmodel}")

@@ -27,6 +27,20 @@ def check_preprocess(eng, max_pixels=None):
     return n_checked
 
 
+def check_preprocess_float(eng):
+    """float32 / float64 volumes (numpy mode of mask.py:153-155 accepts any dtype): differential vs the oracle."""
+    rng = np.random.default_rng(5)
+    base = po.phantom(2, 300, 420, seed=9).astype(np.float64)
+    base += rng.normal(0, 0.37, size=base.shape)  # genuinely fractional HU values
+    for dt in (np.float32, np.float64):
+        vol = base.astype(dt)
+        xi, xf, bb, _ = eng.preprocess(vol)
+        ref_x, ref_bb = po.preprocess(vol, [256, 256])
+        assert xi is None and ref_x.dtype == dt
+        assert np.array_equal(bb, np.asarray(ref_bb, dtype=np.int32)), dt
+        assert np.array_equal(xf, po.normalise(ref_x)), (dt, float(np.abs(xf - po.normalise(ref_x)).max()))
+
+
 def check_reshape(eng):
     g = np.load(GOLD)
     for i in range(int(g["n_rs"])):

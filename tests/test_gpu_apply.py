@@ -145,3 +145,28 @@ def test_apply_is_independent_of_batch_size_and_lanes(gpu_engine):
         assert np.array_equal(gpu_engine.apply(0, vol, batch_size=5), ref)
     finally:
         gpu_engine.set_streams(2)
+
+
+def test_cli_npy_roundtrip(gpu_engine, tmp_path):
+    """`python -m lungmask_amd in.npy out.npy --modelpath ...` (reference tests/test_cli.py, without the DICOM/ITK I/O)."""
+    from lungmask_amd.__main__ import main
+
+    sd = uo.synthetic_state_dict(3)
+    wp, ip, op = tmp_path / "w.pth", tmp_path / "in.npy", tmp_path / "out.npy"
+    torch.save(sd, wp)
+    vol = po.phantom(3, 512, 512, seed=44)
+    np.save(ip, vol)
+    assert main([str(ip), str(op), "--modelpath", str(wp), "--noprogress"]) == 0
+    gpu_engine.load_state_dict(0, sd)
+    assert np.array_equal(np.load(op), gpu_engine.apply(0, vol))
+    with pytest.raises(RuntimeError):
+        main([str(ip), str(op), "--modelpath", str(wp), "--cpu"])
+
+
+def test_apply_float_volume(gpu_engine):
+    sd = uo.synthetic_state_dict(3)
+    gpu_engine.load_state_dict(0, sd)
+    vol = po.phantom(3, 512, 512, seed=45)
+    ref = gpu_engine.apply(0, vol)
+    assert np.array_equal(gpu_engine.apply(0, vol.astype(np.float32)), ref)  # integral HU values: identical result
+    assert np.array_equal(gpu_engine.apply(0, vol.astype(np.float64)), ref)

@@ -14,6 +14,10 @@ def test_preprocess_bit_exact(gpu_engine):
     assert cases.check_preprocess(gpu_engine) >= 8
 
 
+def test_preprocess_float_volumes(gpu_engine):
+    cases.check_preprocess_float(gpu_engine)
+
+
 def test_reshape_mask_bit_exact(gpu_engine):
     assert cases.check_reshape(gpu_engine) >= 10
 

@@ -7,6 +7,10 @@ def test_preprocess_emulated_bit_exact(emu_engine):
     assert cases.check_preprocess(emu_engine) >= 8
 
 
+def test_preprocess_emulated_float_volumes(emu_engine):
+    cases.check_preprocess_float(emu_engine)
+
+
 def test_reshape_mask_emulated_bit_exact(emu_engine):
     assert cases.check_reshape(emu_engine) >= 10
 
