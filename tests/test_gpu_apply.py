@@ -164,9 +164,17 @@ def test_cli_npy_roundtrip(gpu_engine, tmp_path):
 
 
 def test_apply_float_volume(gpu_engine):
+    """float32 / float64 volumes (numpy mode accepts any dtype): pre-processing keeps the fractional resample values
+    (no integer rounding), so labels may differ from the int16 run; the pipeline is checked against the oracle stages."""
     sd = uo.synthetic_state_dict(3)
     gpu_engine.load_state_dict(0, sd)
-    vol = po.phantom(3, 512, 512, seed=45)
-    ref = gpu_engine.apply(0, vol)
-    assert np.array_equal(gpu_engine.apply(0, vol.astype(np.float32)), ref)  # integral HU values: identical result
-    assert np.array_equal(gpu_engine.apply(0, vol.astype(np.float64)), ref)
+    rng = np.random.default_rng(3)
+    base = po.phantom(3, 512, 512, seed=45).astype(np.float64) + rng.normal(0, 0.4, size=(3, 512, 512))
+    for dt in (np.float32, np.float64):
+        vol = base.astype(dt)
+        out = gpu_engine.apply(0, vol)
+        xs, boxes = po.preprocess(vol, [256, 256])
+        lab = gpu_labels(gpu_engine, 0, po.normalise(xs)[:, None])
+        post = po.postprocessing(lab.copy())
+        expect = np.asarray([po.reshape_mask(post[i], boxes[i], vol.shape[1:]) for i in range(len(post))], dtype=np.uint8)
+        assert np.array_equal(out, expect), dt
