@@ -95,3 +95,37 @@ def test_forward_repeatability_stress(gpu_engine):
         gpu_engine.forward_dev(0, xs, l5, lp)
         gpu_engine.sync()
         assert np.array_equal(lp.download(), first), f"iteration {it}"
+
+
+def test_forward_odd_width_fallback_kernel(gpu_engine, precision):
+    """48x48 input: widths 48/24/12/6/3 are neither 16 nor multiples of 32 -> the simple 4-wave kernel with clipped tiles."""
+    sd = uo.synthetic_state_dict(3)
+    gpu_engine.load_state_dict(0, sd)
+    x = np.random.default_rng(23).random((3, 48, 48), dtype=np.float32)
+    lab, logp = gpu_engine.forward(0, x)
+    with torch.inference_mode():
+        ref = uo.forward(sd, torch.from_numpy(x[:, None]))
+    srt = torch.sort(ref, dim=1, descending=True)[0]
+    err = np.abs(logp - ref.numpy()).max()
+    assert err < TOL, err
+    check_labels(lab, ref.argmax(1).numpy().astype(np.uint8), (srt[:, 0] - srt[:, 1]).numpy(), TOL)
+
+
+def test_forward_fallback_kernel_at_full_size():
+    """LM_H3_FALLBACK=1 (read once per process) forces the fallback conv kernel on every level: own process."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "from lungmask_amd import _native as nat\n"
+        "from oracle import unet_oracle as uo\n"
+        "e = nat.Engine(0); sd = uo.synthetic_state_dict(3); e.load_state_dict(0, sd)\n"
+        "x = np.random.default_rng(3).random((2, 256, 256), dtype=np.float32)\n"
+        "lab, logp = e.forward(0, x)\n"
+        "ref = uo.forward(sd, torch.from_numpy(x[:, None])).numpy()\n"
+        "err = float(np.abs(logp - ref).max()); print('ERR', err); assert err < 1e-3\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LM_H3_FALLBACK="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
