@@ -99,6 +99,13 @@ int lm_preprocess_dev(lm_engine* e, const void* vol_dev, int dtype, int n, int h
 int lm_reshape_mask_dev(lm_engine* e, const uint8_t* mask_dev, const int32_t* bbox_dev, int n, int mh, int mw,
                         int h, int w, uint8_t* out_dev);
 
+/* ---- orientation (mask.py:156-164 sitk.DICOMOrient(image, "LPS") and its undo at :204-208) ---- */
+/* Axis permutation / flip as an index transform: out[i0][i1][i2] = in[base + i0*s0 + i1*s1 + i2*s2]
+ * (strides and base in ELEMENTS of elem_size = 1|2|4|8 bytes; strides may be negative; in/out must not
+ * overlap).  The host side derives (s, base) from the image direction cosines (lungmask_amd/volume_io.py). */
+int lm_reorient_dev(lm_engine* e, const void* in_dev, void* out_dev, int elem_size, int n0, int n1, int n2,
+                    int64_t s0, int64_t s1, int64_t s2, int64_t base);
+
 /* ---- volume post-processing (utils.py:272-358 postprocessing incl. :361-404 bbox_3D /
  *      keep_largest_connected_component and the hole filler of :344-352) -------------- */
 /* lab_dev u8 [n][h][w], processed IN PLACE.  spare: label values that are merged into

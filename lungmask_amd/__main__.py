@@ -1,16 +1,15 @@
 """`python -m lungmask_amd INPUT OUTPUT [...]` -- the reference's command line (lungmask/__main__.py:20-144)
 on the MI355X engine.  Same flags; thin by design (all I/O, off the hot path):
 
-* `.npy` / `.npz` volumes are read and written without any imaging dependency;
-* every other format goes through SimpleITK exactly like the reference (imported lazily; this image does not ship
-  it), including the DICOM tag carry-over of `--removemetadata`'s complement;
+* `.npy` / `.npz`, NIfTI-1 (`.nii`, `.nii.gz`), MetaImage (`.mha`, `.mhd`) and uncompressed DICOM (files and series
+  folders) are read -- and all but DICOM written -- by `volume_io.py` without any imaging dependency;
+* every other format goes through SimpleITK like the reference (imported lazily; this image does not ship it),
+  including the DICOM tag carry-over of `--removemetadata`'s complement;
 * `--cpu` is accepted and refused: there is no CPU path in this engine.
 """
 import argparse
 import os
 import sys
-
-import numpy as np
 
 from .logger import logger
 from .mask import LMInferer
@@ -44,38 +43,13 @@ def build_parser():
     return p
 
 
-def _load(path_, keepmetadata):
-    ext = os.path.splitext(path_)[1].lower()
-    if ext == ".npy":
-        return np.load(path_), None
-    if ext == ".npz":
-        z = np.load(path_)
-        return z[z.files[0]], None
-    import SimpleITK as sitk  # utils.load_input_image (utils.py:233-269)
-
-    if os.path.isfile(path_):
-        reader = sitk.ImageFileReader()
-        reader.SetFileName(path_)
-        if keepmetadata:
-            reader.LoadPrivateTagsOn()
-        img = reader.Execute()
-    else:
-        ids = sitk.ImageSeriesReader.GetGDCMSeriesIDs(path_)
-        if not ids:
-            sys.exit("No dicoms found!")
-        best = max(ids, key=lambda s: len(sitk.ImageSeriesReader.GetGDCMSeriesFileNames(path_, s)))
-        reader = sitk.ImageSeriesReader()
-        reader.SetFileNames(sitk.ImageSeriesReader.GetGDCMSeriesFileNames(path_, best))
-        reader.MetaDataDictionaryArrayUpdateOn()
-        img = reader.Execute()
-    return img, img
-
-
 def main(argv=None):
+    from . import volume_io
+
     args = build_parser().parse_args(sys.argv[1:] if argv is None else argv)
     keepmetadata = not args.removemetadata
     logger.info("Load model")
-    image, ref_img = _load(args.input, keepmetadata)
+    image = volume_io.load_input_image(args.input)  # utils.load_input_image (utils.py:233-269)
     logger.info("Infer lungmask")
     if args.modelname == "LTRCLobes_R231":
         assert args.modelpath is None, "Modelpath can not be specified for LTRCLobes_R231 mode"
@@ -86,28 +60,11 @@ def main(argv=None):
                             volume_postprocessing=not args.nopostprocess, tqdm_disable=args.noprogress)
     result = inferer.apply(image)
     logger.info(f"Save result to: {args.output}")
-    ext = os.path.splitext(args.output)[1].lower()
-    if ref_img is None or ext in (".npy", ".npz"):
-        if ext == ".npz":
-            np.savez_compressed(args.output, mask=result)
-        else:
-            np.save(args.output, result)
-        return 0
-    import SimpleITK as sitk
-
-    out = sitk.GetImageFromArray(result)
-    out.CopyInformation(ref_img)
-    writer = sitk.ImageFileWriter()
-    writer.SetFileName(args.output)
-    if keepmetadata:  # __main__.py:125-141
-        writer.SetKeepOriginalImageUID(True)
-        for key in ref_img.GetMetaDataKeys():
-            if key in DICOM_METADATA_TO_KEEP:
-                out.SetMetaData(key, ref_img.GetMetaData(key))
-        out.SetMetaData("0008|103e", "Created with lungmask")
-        out.SetMetaData("0028|1050", "1")
-        out.SetMetaData("0028|1051", "2")
-    writer.Execute(out)
+    keep = None
+    if keepmetadata:  # __main__.py:125-141 (only formats that store tags use them)
+        keep = {k: v for k, v in image.meta.items() if k in DICOM_METADATA_TO_KEEP}
+        keep.update({"0008|103e": "Created with lungmask", "0028|1050": "1", "0028|1051": "2"})
+    volume_io.save_image(args.output, image.like(result), keep)
     return 0
 
 

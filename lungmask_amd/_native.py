@@ -68,6 +68,7 @@ class Library:
         L.lm_forward_batches_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.lm_preprocess_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_int] * 5 + [C.c_void_p] * 4
         L.lm_reshape_mask_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
+        L.lm_reorient_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_int64] * 4
         L.lm_postprocess_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]
         L.lm_postprocess_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.lm_fuse_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]
@@ -269,6 +270,24 @@ class Engine:
         out = od.download()
         for d in (md, bd, od):
             d.free()
+        return out
+
+    # -- orientation
+    def reorient_dev(self, src: DeviceArray, axes, flips) -> DeviceArray:
+        """out = src.transpose(axes) with out-axis k reversed where flips[k] (device index transform)."""
+        in_strides = [int(np.prod(src.shape[a + 1:], dtype=np.int64)) for a in range(3)]
+        shape, strides, base = [], [], 0
+        for k in range(3):
+            a = int(axes[k])
+            shape.append(src.shape[a])
+            if flips[k]:
+                strides.append(-in_strides[a])
+                base += (src.shape[a] - 1) * in_strides[a]
+            else:
+                strides.append(in_strides[a])
+        out = self.empty(tuple(shape), src.dtype)
+        self.L.check(self.L.lib.lm_reorient_dev(self.h, src.ptr, out.ptr, np.dtype(src.dtype).itemsize, *shape, *strides, base),
+                     "lm_reorient_dev")
         return out
 
     # -- post-processing

@@ -195,6 +195,25 @@ int lm_reshape_mask_dev(lm_engine* e, const uint8_t* mask_dev, const int32_t* bb
     return LM_OK;
 }
 
+int lm_reorient_dev(lm_engine* e, const void* in_dev, void* out_dev, int elem_size, int n0, int n1, int n2, int64_t s0, int64_t s1,
+                    int64_t s2, int64_t base) {
+    if (!e || !in_dev || !out_dev || n0 < 0 || n1 < 0 || n2 < 0 || base < 0 ||
+        (elem_size != 1 && elem_size != 2 && elem_size != 4 && elem_size != 8)) {
+        set_error("lm_reorient_dev: bad arguments");
+        return LM_ERR_INVALID;
+    }
+    LM_DEVICE(e);
+    ReorientParams p{in_dev, out_dev, elem_size, n0, n1, n2, (long long)s0, (long long)s1, (long long)s2, (long long)base};
+    e->prof.begin(e->stream, e->prof.kind_id("reorient"), 0, 2.0 * elem_size * (double)n0 * n1 * n2);
+    hipError_t err = launch_reorient(p, e->stream);
+    e->prof.end(e->stream);
+    if (err != hipSuccess) {
+        set_error("reorient launch failed: %s", hipGetErrorString(err));
+        return LM_ERR_DEVICE;
+    }
+    return LM_OK;
+}
+
 int lm_postprocess_dev(lm_engine* e, uint8_t* lab_dev, int n, int h, int w, const int* spare, int n_spare, int skip_below) {
     if (!e || !lab_dev || n < 0 || h <= 0 || w <= 0 || n_spare < 0) {
         set_error("lm_postprocess_dev: bad arguments");

@@ -30,6 +30,17 @@ struct ReshapeParams {
     int N, MH, MW, H, W;
 };
 
+// Axis permutation / flip of a volume (sitk.DICOMOrient at mask.py:156-164,204-208 as an index transform):
+// out[i0][i1][i2] = in[base + i0*s0 + i1*s1 + i2*s2], element strides (may be negative).
+struct ReorientParams {
+    const void* in;
+    void* out;
+    int elem;  // bytes per element: 1, 2, 4 or 8
+    int n0, n1, n2;
+    long long s0, s1, s2, base;
+};
+
+hipError_t launch_reorient(const ReorientParams& p, hipStream_t stream);
 hipError_t launch_bodymask_bbox(const BodyMaskParams& p, hipStream_t stream);
 hipError_t launch_resample_norm(const ResampleParams& p, hipStream_t stream);
 hipError_t launch_reshape_mask(const ReshapeParams& p, hipStream_t stream);

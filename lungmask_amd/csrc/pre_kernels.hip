@@ -397,4 +397,35 @@ hipError_t launch_reshape_mask(const ReshapeParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// reorient: one output element per thread (grid-stride); writes are coalesced, reads follow the
+// source strides (coalesced too whenever the fastest axis is kept, e.g. pure flips).
+template <typename T>
+__global__ void reorient_kernel(ReorientParams p) {
+    const T* __restrict__ in = (const T*)p.in;
+    T* __restrict__ out = (T*)p.out;
+    const size_t total = (size_t)p.n0 * p.n1 * p.n2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int i2 = (int)(i % (size_t)p.n2);
+        const size_t r = i / (size_t)p.n2;
+        const int i1 = (int)(r % (size_t)p.n1);
+        const int i0 = (int)(r / (size_t)p.n1);
+        out[i] = in[p.base + i0 * p.s0 + i1 * p.s1 + i2 * p.s2];
+    }
+}
+
+hipError_t launch_reorient(const ReorientParams& p, hipStream_t stream) {
+    const size_t total = (size_t)p.n0 * p.n1 * p.n2;
+    if (total == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 64);
+    switch (p.elem) {
+        case 1: LM_LAUNCH(reorient_kernel<uint8_t>, dim3(blocks), dim3(256), 0, stream, p); break;
+        case 2: LM_LAUNCH(reorient_kernel<uint16_t>, dim3(blocks), dim3(256), 0, stream, p); break;
+        case 4: LM_LAUNCH(reorient_kernel<uint32_t>, dim3(blocks), dim3(256), 0, stream, p); break;
+        case 8: LM_LAUNCH(reorient_kernel<uint64_t>, dim3(blocks), dim3(256), 0, stream, p); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 }  // namespace lm

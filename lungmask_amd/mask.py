@@ -85,33 +85,51 @@ class LMInferer:
             self.fill_slot = 1
 
     def apply(self, image) -> np.ndarray:
-        """mask.py:212-232 (+ _inference :141-210).  `image`: numpy volume [n,h,w] or SimpleITK image."""
-        numpy_mode = isinstance(image, np.ndarray)
-        curr_orient = "LPS"
-        if numpy_mode:
+        """mask.py:212-232 (+ _inference :141-210).  `image`: numpy volume [n,h,w], a `volume_io.Volume`, or a SimpleITK
+        image.  Images with a direction matrix are brought to LPS and back (mask.py:156-164, 204-208) by an index
+        transform on the device (`lm_reorient_dev`) instead of `sitk.DICOMOrient`."""
+        axes, flips = (0, 1, 2), (False, False, False)
+        if isinstance(image, np.ndarray):
             inimg_raw = image
-        else:  # mask.py:156-164
-            import SimpleITK as sitk
+        else:
+            from . import volume_io
 
-            curr_orient = sitk.DICOMOrientImageFilter_GetOrientationFromDirectionCosines(image.GetDirection())
-            if curr_orient != "LPS":
-                image = sitk.DICOMOrient(image, "LPS")
-            inimg_raw = sitk.GetArrayFromImage(image)
+            if isinstance(image, volume_io.Volume):
+                inimg_raw, direction = image.array, image.direction
+            else:
+                import SimpleITK as sitk
+
+                inimg_raw, direction = sitk.GetArrayFromImage(image), image.GetDirection()
+            if volume_io.orientation_code(direction) != "LPS":
+                axes, flips = volume_io.lps_transform(direction)
         if inimg_raw.dtype not in (np.int16, np.int32, np.int64, np.float32, np.float64):
-            if inimg_raw.dtype.kind == "i" or inimg_raw.dtype == np.uint8:
-                inimg_raw = inimg_raw.astype(np.int32)  # value preserving; np.clip(-1024, 600) then behaves as for int32
+            if inimg_raw.dtype.kind == "i" or inimg_raw.dtype.kind == "u" and inimg_raw.dtype.itemsize < 8:
+                # value preserving; np.clip(-1024, 600) then behaves as for a wider signed type
+                inimg_raw = inimg_raw.astype(np.int32 if inimg_raw.dtype.itemsize < 4 else np.int64)
             else:
                 raise TypeError(f"lungmask_amd: unsupported volume dtype {inimg_raw.dtype}")
         if self.fillmodel is not None:
             logger.info(f"Apply: {self.modelname}")
             logger.info(f"Apply: {self.fillmodel}")
             logger.info("Fusing results... this may take up to several minutes!")
-        outmask = self.engine.apply(0, inimg_raw, fill_slot=self.fill_slot, batch_size=self.batch_size,
-                                    volume_postprocessing=self.volume_postprocessing)
-        if not numpy_mode and curr_orient != "LPS":  # mask.py:204-208
-            import SimpleITK as sitk
+        if axes == (0, 1, 2) and not any(flips):
+            outmask = self.engine.apply(0, inimg_raw, fill_slot=self.fill_slot, batch_size=self.batch_size,
+                                        volume_postprocessing=self.volume_postprocessing)
+        else:
+            from . import volume_io
 
-            outmask = sitk.GetArrayFromImage(sitk.DICOMOrient(sitk.GetImageFromArray(outmask), curr_orient))
+            eng = self.engine
+            raw = eng.to_device(np.ascontiguousarray(inimg_raw))
+            lps = eng.reorient_dev(raw, axes, flips)
+            raw.free()
+            out_lps = eng.empty(lps.shape, np.uint8)
+            eng.apply_dev(0, lps, out_lps, fill_slot=self.fill_slot, batch_size=self.batch_size,
+                          volume_postprocessing=self.volume_postprocessing)
+            back = eng.reorient_dev(out_lps, *volume_io.inverse_transform(axes, flips))
+            eng.sync()
+            outmask = back.download()
+            for d in (lps, out_lps, back):
+                d.free()
         return outmask.astype(np.uint8)
 
 

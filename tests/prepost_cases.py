@@ -90,3 +90,24 @@ def check_fuse(eng):
     assert spare == int(sv) and np.array_equal(fused, ref)
     out = eng.postprocess(fused, spare=[spare])
     assert np.array_equal(out, po.fuse(res_l, res_r))
+
+
+def check_reorient(engine):
+    """lm_reorient_dev == a.transpose(axes) with per-axis flips (the device form of sitk.DICOMOrient, mask.py:156-164,204-208)."""
+    import itertools
+
+    from lungmask_amd import volume_io as vio
+
+    rng = np.random.default_rng(5)
+    for dt in (np.uint8, np.int16, np.float32, np.float64):
+        a = rng.integers(0, 250, (3, 5, 7)).astype(dt)
+        d = engine.to_device(a)
+        for axes in itertools.permutations(range(3)):
+            for flips in itertools.product((False, True), repeat=3):
+                o = engine.reorient_dev(d, axes, flips)
+                engine.sync()
+                got = o.download()
+                o.free()
+                assert np.array_equal(got, vio.apply_transform(a, axes, flips)), (dt, axes, flips)
+                assert np.array_equal(vio.apply_transform(got, *vio.inverse_transform(axes, flips)), a)
+        d.free()

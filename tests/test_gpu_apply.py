@@ -178,3 +178,47 @@ def test_apply_float_volume(gpu_engine):
         post = po.postprocessing(lab.copy())
         expect = np.asarray([po.reshape_mask(post[i], boxes[i], vol.shape[1:]) for i in range(len(post))], dtype=np.uint8)
         assert np.array_equal(out, expect), dt
+
+
+def test_oriented_volumes_and_image_file_formats(gpu_engine, tmp_path):
+    """mask.py:156-164,204-208: images that are not LPS are re-oriented, segmented and oriented back (here on the device);
+    CLI on NIfTI / MetaImage / DICOM-folder input (utils.load_input_image) with the geometry carried to the output."""
+    from lungmask_amd import LMInferer
+    from lungmask_amd import volume_io as vio
+    from lungmask_amd.__main__ import main
+    from test_volume_io import write_dicom
+
+    sd = uo.synthetic_state_dict(3)
+    wp = tmp_path / "w.pth"
+    torch.save(sd, wp)
+    gpu_engine.load_state_dict(0, sd)
+    lps = po.phantom(4, 512, 512, seed=45)
+    expect = gpu_engine.apply(0, lps)
+    inferer = LMInferer(modelpath=str(wp), tqdm_disable=True)
+    # (1) typical NIfTI storage (RAS: x and y reversed) and a coronal stack (index axes x, z, y)
+    ras = vio.Volume(lps[:, ::-1, ::-1].copy(), (0.7, 0.7, 1.5), (100, 120, -30), np.diag([-1.0, -1.0, 1.0]))
+    assert vio.orientation_code(ras.direction) == "RAS"
+    assert np.array_equal(inferer.apply(ras), expect[:, ::-1, ::-1])
+    d = np.zeros((3, 3))
+    d[0, 0], d[2, 1], d[1, 2] = 1, -1, 1  # index x -> L, index y -> I, index z -> P
+    cor = vio.Volume(lps.transpose(1, 0, 2)[:, ::-1, :].copy(), (0.7, 1.5, 0.7), (0, 0, 0), d)
+    assert vio.orientation_code(cor.direction) == "LIP"
+    assert np.array_equal(inferer.apply(cor), expect.transpose(1, 0, 2)[:, ::-1, :])
+    assert np.array_equal(inferer.apply(vio.Volume(lps)), expect)
+    # (2) files: NIfTI in -> NIfTI out, MetaImage in -> MetaImage out, DICOM folder in -> npy out
+    for ext in (".nii.gz", ".mha"):
+        ip, op = str(tmp_path / ("in" + ext)), str(tmp_path / ("out" + ext))
+        vio.save_image(ip, ras)
+        assert main([ip, op, "--modelpath", str(wp), "--noprogress"]) == 0
+        got = vio.load_input_image(op)
+        assert got.array.dtype == np.uint8 and np.array_equal(got.array, expect[:, ::-1, ::-1])
+        np.testing.assert_allclose(got.direction, ras.direction, atol=1e-6)
+        np.testing.assert_allclose(got.spacing, ras.spacing, rtol=1e-6)
+        np.testing.assert_allclose(got.origin, ras.origin, rtol=1e-6)
+    dd = tmp_path / "dicoms"
+    dd.mkdir()
+    for k in (3, 1, 0, 2):
+        write_dicom(dd / f"s{k}.dcm", lps[k], (0.0, 0.0, 1.5 * k))
+    op = str(tmp_path / "from_dicom.npy")
+    assert main([str(dd), op, "--modelpath", str(wp), "--noprogress"]) == 0
+    assert np.array_equal(np.load(op), expect)

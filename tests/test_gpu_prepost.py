@@ -42,6 +42,10 @@ def test_fusion(gpu_engine):
     cases.check_fuse(gpu_engine)
 
 
+def test_reorient(gpu_engine):
+    cases.check_reorient(gpu_engine)
+
+
 def test_preprocess_phantom_slices_vs_oracle(gpu_engine):
     vol = po.phantom(6, 512, 512)
     xi, xf, bb, _ = gpu_engine.preprocess(vol)

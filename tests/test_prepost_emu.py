@@ -25,3 +25,7 @@ def test_postprocessing_emulated_random_differential(emu_engine):
 
 def test_fusion_emulated(emu_engine):
     cases.check_fuse(emu_engine)
+
+
+def test_reorient_emulated(emu_engine):
+    cases.check_reorient(emu_engine)

@@ -1,0 +1,214 @@
+"""Host-side volume I/O and orientation (reference: utils.load_input_image / read_dicoms utils.py:132-269,
+mask.py:156-164,204-208).  SimpleITK is not installed here, so the checks are format round trips, hand-built
+files, physical-position invariants and -- when /root/reference is mounted -- the reference's own DICOM fixtures."""
+import gzip
+import itertools
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from lungmask_amd import volume_io as vio
+
+
+def _rot(axis, deg):
+    t = np.deg2rad(deg)
+    c, s = np.cos(t), np.sin(t)
+    m = {0: [[1, 0, 0], [0, c, -s], [0, s, c]], 1: [[c, 0, s], [0, 1, 0], [-s, 0, c]], 2: [[c, -s, 0], [s, c, 0], [0, 0, 1]]}[axis]
+    return np.asarray(m, dtype=np.float64)
+
+
+def test_orientation_codes():
+    assert vio.orientation_code(np.eye(3)) == "LPS"
+    assert vio.orientation_code(np.diag([-1.0, -1.0, 1.0])) == "RAS"
+    assert vio.orientation_code(np.diag([1.0, -1.0, -1.0])) == "LAI"
+    d = np.zeros((3, 3))  # x index axis runs towards Superior, y towards Left, z towards Anterior
+    d[2, 0], d[0, 1], d[1, 2] = 1, 1, -1
+    assert vio.orientation_code(d) == "SLA"
+    assert vio.orientation_code(_rot(2, 20) @ _rot(0, -15)) == "LPS"  # oblique but dominated by the identity
+
+
+def test_every_axis_permutation_and_flip_round_trips():
+    rng = np.random.default_rng(0)
+    a = rng.integers(-100, 100, (3, 4, 5)).astype(np.int16)
+    for perm in itertools.permutations(range(3)):
+        for signs in itertools.product((1, -1), repeat=3):
+            d = np.zeros((3, 3))
+            for c in range(3):
+                d[perm[c], c] = signs[c]
+            d = _rot(1, 7) @ d  # slightly oblique
+            vol = vio.Volume(a, spacing=(0.7, 0.8, 2.5), origin=(10, -20, 30), direction=d)
+            axes, flips = vio.lps_transform(d)
+            lps = vio.reoriented_geometry(vol, axes, flips)
+            assert vio.orientation_code(lps.direction) == "LPS"
+            # every voxel keeps its value at its physical position
+            for _ in range(10):
+                k, j, i = (int(rng.integers(0, n)) for n in lps.array.shape)
+                p = lps.index_to_physical((i, j, k))
+                ijk = np.linalg.solve(vol.direction * np.asarray(vol.spacing)[None, :], p - np.asarray(vol.origin))
+                ii, jj, kk = (int(round(v)) for v in ijk)
+                assert lps.array[k, j, i] == a[kk, jj, ii]
+            back = vio.apply_transform(lps.array, *vio.inverse_transform(axes, flips))
+            assert np.array_equal(back, a)
+
+
+@pytest.mark.parametrize("ext", [".nii", ".nii.gz", ".mha", ".mhd"])
+def test_round_trip_formats(tmp_path, ext):
+    rng = np.random.default_rng(1)
+    for dt in (np.int16, np.uint8, np.float32):
+        a = rng.integers(0, 200, (4, 6, 5)).astype(dt)
+        d = _rot(2, 10) @ np.diag([-1.0, 1.0, -1.0])
+        vol = vio.Volume(a, (0.5, 0.75, 3.0), (12.5, -7.0, 100.0), d)
+        path = str(tmp_path / ("v" + ext))
+        vio.save_image(path, vol)
+        got = vio.load_input_image(path)
+        assert got.array.dtype == dt and np.array_equal(got.array, a)
+        np.testing.assert_allclose(got.spacing, vol.spacing, rtol=1e-6)
+        np.testing.assert_allclose(got.origin, vol.origin, rtol=1e-6)
+        np.testing.assert_allclose(got.direction, d, atol=1e-6)
+
+
+def _nifti_header(en, shape_xyz, code, bitpix, qform=0, sform=0, quat=(0, 0, 0), qoff=(0, 0, 0), pixdim=(1, 1, 1, 1), srow=None, slope=0.0, inter=0.0):
+    h = bytearray(352)
+    struct.pack_into(en + "i", h, 0, 348)
+    struct.pack_into(en + "8h", h, 40, 3, *shape_xyz, 1, 1, 1, 1)
+    struct.pack_into(en + "hh", h, 70, code, bitpix)
+    struct.pack_into(en + "8f", h, 76, *pixdim, 0, 0, 0, 0)
+    struct.pack_into(en + "3f", h, 108, 352.0, slope, inter)
+    struct.pack_into(en + "2h", h, 252, qform, sform)
+    struct.pack_into(en + "6f", h, 256, *quat, *qoff)
+    if srow is not None:
+        struct.pack_into(en + "12f", h, 280, *np.asarray(srow, dtype=np.float64).reshape(-1))
+    h[344:348] = b"n+1\0"
+    return bytes(h)
+
+
+def test_nifti_hand_built_headers(tmp_path):
+    a = np.arange(2 * 3 * 4, dtype=np.int16).reshape(2, 3, 4)
+    # (1) big-endian, no qform/sform: RAS identity -> direction diag(-1,-1,1) in LPS
+    p = tmp_path / "be.nii"
+    p.write_bytes(_nifti_header(">", (4, 3, 2), 4, 16, pixdim=(1, 0.5, 0.6, 2.0)) + a.astype(">i2").tobytes())
+    v = vio.read_nifti(str(p))
+    assert np.array_equal(v.array, a) and v.array.dtype == np.int16
+    assert vio.orientation_code(v.direction) == "RAS" and v.spacing == pytest.approx((0.5, 0.6, 2.0))
+    # (2) qform: 180 degrees about z (b=c=0, d=1) in RAS == identity in LPS; qfac=-1 flips the third axis
+    p = tmp_path / "q.nii.gz"
+    p.write_bytes(gzip.compress(_nifti_header("<", (4, 3, 2), 4, 16, qform=1, quat=(0, 0, 1), qoff=(5, 6, 7), pixdim=(-1, 1, 1, 1)) + a.tobytes()))
+    v = vio.read_nifti(str(p))
+    np.testing.assert_allclose(v.direction, np.diag([1.0, 1.0, -1.0]), atol=1e-6)
+    assert vio.orientation_code(v.direction) == "LPI" and v.origin == pytest.approx((-5, -6, 7))
+    # (3) sform only, with scaling; (4) scl_slope/inter rescale into floating point
+    srow = [[-0.7, 0, 0, 90], [0, 0, 2.5, -100], [0, -0.8, 0, 30]]
+    p = tmp_path / "s.nii"
+    p.write_bytes(_nifti_header("<", (4, 3, 2), 4, 16, sform=2, srow=srow, slope=2.0, inter=-1024.0) + a.tobytes())
+    v = vio.read_nifti(str(p))
+    assert v.spacing == pytest.approx((0.7, 0.8, 2.5)) and v.origin == pytest.approx((-90, 100, 30))
+    assert vio.orientation_code(v.direction) == "LIA"
+    assert v.array.dtype == np.float32 and np.array_equal(v.array, a.astype(np.float32) * 2 - 1024)
+    with pytest.raises(ValueError):
+        bad = tmp_path / "bad.nii"
+        bad.write_bytes(b"\0" * 400)
+        vio.read_nifti(str(bad))
+
+
+# ---- DICOM ------------------------------------------------------------------------------------
+def _el(tag, vr, value, explicit=True):
+    g, e = tag
+    if isinstance(value, str):
+        value = value.encode("ascii")
+    if len(value) % 2:
+        value += b"\0" if vr == "UI" else b" "
+    if not explicit:
+        return struct.pack("<HHI", g, e, len(value)) + value
+    if vr in ("OB", "OW", "SQ", "UN", "UT"):
+        return struct.pack("<HH2sHI", g, e, vr.encode(), 0, len(value)) + value
+    return struct.pack("<HH2sH", g, e, vr.encode(), len(value)) + value
+
+
+def write_dicom(path, pixels, ipp, series="1.2.3.4", study="1.2.3", image_type="ORIGINAL\\PRIMARY\\AXIAL", explicit=True, intercept=0,
+                signed=1, iop="1\\0\\0\\0\\1\\0", with_sequence=False):
+    ts = "1.2.840.10008.1.2.1" if explicit else "1.2.840.10008.1.2"
+    meta = _el((2, 0x10), "UI", ts)
+    meta = _el((2, 0), "UL", struct.pack("<I", len(meta))) + meta
+    ds = b""
+    if image_type is not None:
+        ds += _el((8, 8), "CS", image_type, explicit)
+    ds += _el((8, 0x20), "DA", "20240102", explicit)
+    if with_sequence:  # an undefined-length sequence with one undefined-length item holding a nested element
+        inner = _el((8, 0x100), "SH", "CODE", explicit)
+        item = struct.pack("<HHI", 0xFFFE, 0xE000, 0xFFFFFFFF) + inner + struct.pack("<HHI", 0xFFFE, 0xE00D, 0)
+        seq = item + struct.pack("<HHI", 0xFFFE, 0xE0DD, 0)
+        ds += (struct.pack("<HH2sHI", 8, 0x1140, b"SQ", 0, 0xFFFFFFFF) if explicit else struct.pack("<HHI", 8, 0x1140, 0xFFFFFFFF)) + seq
+    ds += _el((0x10, 0x10), "PN", "Doe^Jane", explicit)
+    ds += _el((0x20, 0xD), "UI", study, explicit) + _el((0x20, 0xE), "UI", series, explicit)
+    ds += _el((0x20, 0x32), "DS", "\\".join(str(v) for v in ipp), explicit) + _el((0x20, 0x37), "DS", iop, explicit)
+    ds += _el((0x28, 2), "US", struct.pack("<H", 1), explicit)
+    ds += _el((0x28, 0x10), "US", struct.pack("<H", pixels.shape[0]), explicit) + _el((0x28, 0x11), "US", struct.pack("<H", pixels.shape[1]), explicit)
+    ds += _el((0x28, 0x30), "DS", "0.8\\0.6", explicit)
+    ds += _el((0x28, 0x100), "US", struct.pack("<H", 16), explicit) + _el((0x28, 0x101), "US", struct.pack("<H", 16), explicit)
+    ds += _el((0x28, 0x103), "US", struct.pack("<H", signed), explicit)
+    ds += _el((0x28, 0x1052), "DS", str(intercept), explicit) + _el((0x28, 0x1053), "DS", "1", explicit)
+    ds += _el((0x7FE0, 0x10), "OW", pixels.astype("<i2" if signed else "<u2").tobytes(), explicit)
+    with open(path, "wb") as f:
+        f.write(b"\0" * 128 + b"DICM" + meta + ds)
+
+
+@pytest.mark.parametrize("explicit", [True, False])
+def test_dicom_series_logic(tmp_path, explicit):
+    rng = np.random.default_rng(2)
+    sl = [rng.integers(-1000, 1000, (6, 5)).astype(np.int16) for _ in range(4)]
+    d = tmp_path / "study"
+    (d / "sub").mkdir(parents=True)
+    # main series: written out of order, one duplicate under another name, one localizer, one file without ImageType
+    for k in (2, 0, 3, 1):
+        write_dicom(d / f"im{k}.dcm", sl[k], (1.0, 2.0, 10.0 + 2.5 * k), explicit=explicit, with_sequence=(k == 0))
+    write_dicom(d / "sub" / "copy_of_1.dcm", sl[1], (1.0, 2.0, 12.5), explicit=explicit)
+    write_dicom(d / "loc.dcm", sl[0], (0, 0, -50.0), image_type="ORIGINAL\\PRIMARY\\LOCALIZER", explicit=explicit)
+    write_dicom(d / "notype.dcm", sl[0], (0, 0, -60.0), image_type=None, explicit=explicit)
+    # a smaller second series and a non-DICOM file
+    write_dicom(d / "other.dcm", sl[0], (0, 0, 0), series="1.2.3.5", explicit=explicit)
+    (d / "readme.txt").write_text("not dicom at all, but longer than eight bytes")
+    v = vio.load_input_image(str(d))
+    assert v.array.shape == (4, 6, 5) and v.array.dtype == np.int16
+    for k in range(4):
+        assert np.array_equal(v.array[k], sl[k])
+    assert v.spacing == pytest.approx((0.6, 0.8, 2.5)) and v.origin == pytest.approx((1.0, 2.0, 10.0))
+    assert vio.orientation_code(v.direction) == "LPS"
+    assert v.meta["0010|0010"].strip() == "Doe^Jane" and v.meta["0008|0020"] == "20240102"
+    assert len(vio.read_dicoms(str(d), primary=False, original=False)) == 2
+
+
+def test_dicom_rescale_and_feet_first(tmp_path):
+    px = np.arange(30, dtype=np.uint16).reshape(6, 5) + 1000
+    d = tmp_path / "s"
+    d.mkdir()
+    for k in range(3):  # z decreases with the instance index; sorting by position restores ascending z
+        write_dicom(d / f"{k}.dcm", px + k, (0, 0, -5.0 * k), signed=0, intercept=-1024)
+    v = vio.load_input_image(str(d))
+    assert v.array.dtype == np.int32  # unsigned 16 bit stored, shifted: does not fit int16 for the full stored range
+    assert np.array_equal(v.array[0], px.astype(np.int32) + 2 - 1024) and np.array_equal(v.array[2], px.astype(np.int32) - 1024)
+    assert v.origin == pytest.approx((0, 0, -10.0)) and v.spacing[2] == pytest.approx(5.0)
+    one = vio.load_input_image(str(d / "1.dcm"))
+    assert one.array.shape == (1, 6, 5)
+
+
+def test_dicom_compressed_is_refused_without_simpleitk(tmp_path):
+    p = tmp_path / "c.dcm"
+    meta = _el((2, 0x10), "UI", "1.2.840.10008.1.2.4.70")
+    meta = _el((2, 0), "UL", struct.pack("<I", len(meta))) + meta
+    ds = _el((8, 8), "CS", "ORIGINAL\\PRIMARY") + struct.pack("<HH2sHI", 0x7FE0, 0x10, b"OB", 0, 0xFFFFFFFF)
+    p.write_bytes(b"\0" * 128 + b"DICM" + meta + ds)
+    with pytest.raises((vio.DicomError, ImportError)):
+        vio.load_input_image(str(p))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/tests/testdata"), reason="reference fixtures not mounted")
+def test_reference_dicom_fixtures():
+    """tests/testdata/{0,1}.dcm of the reference (built by tests/test_utils.py:18-55): int16 512x512 each."""
+    v = vio.load_input_image("/root/reference/tests/testdata")
+    assert v.array.shape == (2, 512, 512) and v.array.dtype == np.int16
+    assert v.spacing[:2] == pytest.approx((0.625, 0.625)) and vio.orientation_code(v.direction) == "LPS"
+    for k, name in enumerate(sorted(os.listdir("/root/reference/tests/testdata"))):
+        raw = np.fromfile(os.path.join("/root/reference/tests/testdata", name), dtype="<i2", count=512 * 512, offset=910).reshape(512, 512)
+        assert any(np.array_equal(v.array[j], raw) for j in range(2))
