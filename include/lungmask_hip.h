@@ -114,6 +114,23 @@ int lm_postprocess_dev(lm_engine* e, uint8_t* lab_dev, int n, int h, int w, cons
                        int skip_below);
 /* What the last lm_postprocess_dev saw: info[0]=regions, [1]=boundary voxels shipped to the
  * host, [2]=regions processed by the merge loop, [3]=regions merged, [4]=host replay in us. */
+/* ---- the same post-processing with the volume's slices spread over `world` ranks (multi-GPU pipeline) ----
+ * Every rank holds a contiguous slab lab_slab_dev u8 [n][h][w] = slices [z0, z0+n) of a volume of n_total slices and
+ * runs the voxel passes on its slab only; the slabs are tied together by six small exchanges the CALLER performs
+ * (torch.distributed all_gather over RCCL; csrc/slab_engine.hip describes each).  Protocol, identical on every rank:
+ *     lm_slab_begin(...);
+ *     do { len = lm_slab_pending(e);                       // int32 words this rank contributes
+ *          all-gather len -> lens[world];  stride = max(lens);
+ *          lm_slab_emit(e, mine_dev);                       // device buffer of >= len words
+ *          all-gather mine_dev (padded to stride) -> gathered_dev [world][stride];
+ *     } while (lm_slab_step(e, gathered_dev, stride, lens) == 0);   // 1 = finished: the slab holds the result
+ * Requires n >= 1 on every rank.  Result == lm_postprocess_dev on the gathered volume, bit for bit. */
+int lm_slab_begin(lm_engine* e, uint8_t* lab_slab_dev, int n, int h, int w, int rank, int world, int z0, int n_total,
+                  const int* spare, int n_spare, int skip_below);
+int64_t lm_slab_pending(lm_engine* e);
+int lm_slab_emit(lm_engine* e, int32_t* dst_dev);
+int lm_slab_step(lm_engine* e, const int32_t* gathered_dev, int64_t stride, const int64_t* lens);
+
 int lm_postprocess_info(lm_engine* e, int64_t info[5]);
 
 /* ---- label fusion (mask.py:228-230): res_l <- fuse(res_l, res_r); returns the spare label -- */

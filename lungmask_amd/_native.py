@@ -70,6 +70,11 @@ class Library:
         L.lm_reshape_mask_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
         L.lm_reorient_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_int64] * 4
         L.lm_postprocess_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]
+        L.lm_slab_begin.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.POINTER(C.c_int), C.c_int, C.c_int]
+        L.lm_slab_pending.argtypes = [C.c_void_p]
+        L.lm_slab_pending.restype = C.c_int64
+        L.lm_slab_emit.argtypes = [C.c_void_p, C.c_void_p]
+        L.lm_slab_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         L.lm_postprocess_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.lm_fuse_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]
         L.lm_apply_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]

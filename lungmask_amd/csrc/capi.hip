@@ -62,6 +62,7 @@ void lm_engine_destroy(lm_engine* e) {
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->stream2) (void)hipStreamDestroy(e->stream2);
     e->post.release();
+    e->slab.release();
     e->app.release();
     (void)hipStreamDestroy(e->stream);
     delete e;
@@ -221,6 +222,31 @@ int lm_postprocess_dev(lm_engine* e, uint8_t* lab_dev, int n, int h, int w, cons
     }
     LM_DEVICE(e);
     return postprocess(e, lab_dev, n, h, w, spare, n_spare, skip_below);
+}
+
+int lm_slab_begin(lm_engine* e, uint8_t* lab_slab_dev, int n, int h, int w, int rank, int world, int z0, int n_total, const int* spare,
+                  int n_spare, int skip_below) {
+    if (!e || !lab_slab_dev || n_spare < 0) {
+        set_error("lm_slab_begin: bad arguments");
+        return LM_ERR_INVALID;
+    }
+    LM_DEVICE(e);
+    return slab_begin(e, lab_slab_dev, n, h, w, rank, world, z0, n_total, spare, n_spare, skip_below);
+}
+
+int64_t lm_slab_pending(lm_engine* e) { return (e && e->slab.phase >= 0) ? (int64_t)e->slab.pending : -1; }
+
+int lm_slab_emit(lm_engine* e, int32_t* dst_dev) {
+    if (!e) return LM_ERR_INVALID;
+    LM_DEVICE(e);
+    return slab_emit(e, dst_dev);
+}
+
+int lm_slab_step(lm_engine* e, const int32_t* gathered_dev, int64_t stride, const int64_t* lens) {
+    if (!e) return LM_ERR_INVALID;
+    LM_DEVICE(e);
+    static_assert(sizeof(long long) == sizeof(int64_t), "");
+    return slab_step(e, gathered_dev, (long long)stride, reinterpret_cast<const long long*>(lens));
 }
 
 int lm_postprocess_info(lm_engine* e, int64_t info[5]) {

@@ -111,6 +111,22 @@ struct ApplyWorkspace {
     void release() { vol.release(); xf.release(); bbox.release(); labels.release(); res_r.release(); out.release(); }
 };
 
+// Slab-sharded post-processing (slab_engine.hip): state between the exchange points of lm_slab_*.
+struct SlabState {
+    int rank = 0, world = 1, n = 0, H = 0, W = 0, z0 = 0, n_total = 0, skip_below = 3;
+    std::vector<int> spare;
+    int phase = -1;          // next lm_slab_step to run (0..5); -1 = idle
+    uint8_t* lab = nullptr;  // the caller's slab (device); receives the result
+    int n1 = 0, n2 = 0;
+    std::vector<int> labels, n3;  // label values with a kept component; atoms of each label's background labelling
+    DevBuf ids2, ids3, first, flags, edges, pack, keeplut, holelut;
+    long long pending = 0;  // ints of `pack` this rank contributes to the next exchange
+    std::vector<std::vector<int>> tables;  // host copies of the gathered tables
+    void release() {
+        ids2.release(); ids3.release(); first.release(); flags.release(); edges.release(); pack.release(); keeplut.release(); holelut.release();
+    }
+};
+
 // What the last lm_postprocess_dev call saw (reported by bench.py next to the timing: it is data dependent).
 struct PostInfo {
     long long regions = 0, boundary_records = 0, merged = 0, processed = 0;
@@ -134,6 +150,7 @@ struct lm_engine {
     lm::PostWorkspace post;
     lm::ApplyWorkspace app;
     lm::PostInfo post_info;
+    lm::SlabState slab;
     lm::Profiler prof;
     int precision = 1;  // 1 (default): split-f16 3-product; 0: exact fp32 matrix ops (lm_set_precision)
     char* zero_page = nullptr;
@@ -145,6 +162,12 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
 // n slices in batches of `batch` (mask.py:173-187), batches alternating over the engine's forward lanes
 int forward_batches(lm_engine* e, int slot, const float* x, int n, int H, int W, int batch, uint8_t* labels);
 int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spare, int n_spare, int skip_below);
+struct BoundaryRec;
+void replay_merge(int R, const int* area, const uint8_t* lv, const BoundaryRec* recs, size_t nrecs, const std::vector<int>& spare, int skip_below,
+                  std::vector<uint8_t>& lut, PostInfo& info);
+int slab_begin(lm_engine* e, uint8_t* lab, int n, int h, int w, int rank, int world, int z0, int n_total, const int* spare, int n_spare, int skip_below);
+int slab_emit(lm_engine* e, int32_t* dst);
+int slab_step(lm_engine* e, const int32_t* gathered, long long stride, const long long* lens);
 int apply_volume(lm_engine* e, int slot, int fill_slot, const void* vol_dev, int dtype, int n, int h, int w, int batch_size,
                  int volume_postprocessing, uint8_t* out_dev);
 }  // namespace lm

@@ -38,6 +38,8 @@ struct ProfScope {
     ~ProfScope() { e->prof.end(e->stream); }
 };
 
+}  // namespace
+
 // utils.py:303-342 on the region graph.  Returns lut[atom] = final label value (0 = removed).
 void replay_merge(int R, const int* area, const uint8_t* lv, const BoundaryRec* recs, size_t nrecs, const std::vector<int>& spare,
                   int skip_below, std::vector<uint8_t>& lut, PostInfo& info) {
@@ -98,7 +100,8 @@ void replay_merge(int R, const int* area, const uint8_t* lv, const BoundaryRec* 
                 stamp[j] = r;
                 const int n = setid[find(recs[j].atom)];
                 if (n == r) continue;
-                if (counts[n]++ == 0) touched.push_back(n);
+                if (counts[n] == 0) touched.push_back(n);
+                counts[n] += recs[j].count;  // `count` voxels share this record
             }
         }
         std::sort(touched.begin(), touched.end());  // np.unique is sorted
@@ -132,8 +135,6 @@ void replay_merge(int R, const int* area, const uint8_t* lv, const BoundaryRec* 
         lut[a] = v;
     }
 }
-
-}  // namespace
 
 int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spare_p, int n_spare, int skip_below) {
     if (N <= 0 || H <= 0 || W <= 0) return LM_OK;

@@ -12,10 +12,13 @@ struct Dims {
     __host__ __device__ size_t nvox() const { return (size_t)N * H * W; }
 };
 
-// One boundary voxel: its atom (initial region id) and the distinct other atoms among its 6 neighbours.
+// A class of boundary voxels: `count` voxels of region `atom` whose 6-neighbourhood holds exactly the distinct other
+// regions nb[] (descending, zero padded).  Identical voxels are merged per workgroup before they leave the device
+// (a 300-slice volume has ~2x10^5 boundary voxels but only ~10^3-10^4 distinct classes).
 struct BoundaryRec {
     int atom;
     int nb[6];
+    int count;
 };
 
 // ---- connected components (union-find on an int32 parent volume; root = first voxel in raster order)
@@ -43,6 +46,29 @@ hipError_t flag_large_components(const int* bgparent, int* flags, int threshold,
 // out[v] = label where v is in the kept component or in an unflagged background component.
 hipError_t fill_write(const int* parent, int keep_root, const int* bgparent, const int* flags, uint8_t label, uint8_t* out, size_t nvox,
                       hipStream_t s);
+
+// ---- slab-sharded post-processing (slab_engine.hip): the same passes on ONE rank's slices, plus the few
+//      planes/tables that tie the slabs together.  "atom" = component of the slab-local labelling (dense id).
+// Halo neighbours in boundary records are tagged: id | HALO_LO (atom of the previous rank's last slice) or
+// id | HALO_HI (atom of the next rank's first slice).
+constexpr int HALO_LO = 1 << 29, HALO_HI = 1 << 30, HALO_MASK = HALO_LO | HALO_HI;
+// halo_lo / halo_hi: int32 [H][W] atom ids of the adjacent slices of the neighbouring slabs (or nullptr).
+hipError_t boundary_records_halo(const int* ids, Dims d, const int* halo_lo, const int* halo_hi, BoundaryRec* recs, unsigned* count_dev,
+                                 unsigned cap, hipStream_t s);
+// first[id] = voxel_base + (index of the first voxel of atom id) -- the key regions are numbered by.
+hipError_t atom_first(const int* parent, const int* rank, int* first, int voxel_base, size_t nvox, hipStream_t s);
+// flags[id] = 1 for atoms with a voxel on a lateral face, on z == 0 (if zlo_face) or on z == N-1 (if zhi_face).
+hipError_t atom_face_flags(const int* ids, Dims d, bool zlo_face, bool zhi_face, int* flags, hipStream_t s);
+// Pairs (atom of plane a, atom of plane b) of voxels that are neighbours across the slab face (straight across, or
+// the 9 of 26-connectivity) and carry the same label (lab_* == nullptr: any two non-zero ids).  Runs are deduplicated.
+hipError_t face_edges(const int* ids_a, const int* lab_a, const int* ids_b, const int* lab_b, int H, int W, bool conn26, int* edges,
+                      unsigned* count_dev, unsigned cap, hipStream_t s);
+hipError_t widen_u8(const uint8_t* in, int* out, size_t n, hipStream_t s);
+// bg[v] = (keeplut[ids[v]] != label)
+hipError_t lut_complement(const int* ids, const uint8_t* keeplut, uint8_t label, uint8_t* bg, size_t nvox, hipStream_t s);
+// out[v] = label where keeplut[ids2[v]] == label or holelut[ids3[v]] != 0
+hipError_t fill_write_lut(const int* ids2, const uint8_t* keeplut, const int* ids3, const uint8_t* holelut, uint8_t label, uint8_t* out,
+                          size_t nvox, hipStream_t s);
 
 // ---- fusion (mask.py:228-230)
 hipError_t volume_max(const uint8_t* a, unsigned* max_dev, size_t nvox, hipStream_t s);

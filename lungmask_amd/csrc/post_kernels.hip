@@ -242,35 +242,125 @@ __global__ __launch_bounds__(TPB) void region_stats_kernel(const int* __restrict
     });
 }
 
-__global__ __launch_bounds__(TPB) void boundary_records_kernel(const int* __restrict__ ids, Dims d, BoundaryRec* recs, unsigned* count, unsigned cap) {
+// Boundary voxel classes.  Each workgroup walks a contiguous range of the volume in tiles of TPB voxels and merges
+// identical records (same atom, same neighbour set) in an LDS hash table before anything is written: slots are
+// claimed with a CAS on a tag word, the claimant writes the 7-int key, and -- after a barrier -- the other threads
+// that met the same tag compare the FULL key (no probabilistic matching, no spinning).  A record that is still
+// unplaced after RROUNDS probes is written out on its own with count 1, so the result is exact in every case.
+constexpr int RH = 512;     // hash slots per workgroup
+constexpr int RROUNDS = 4;  // probes before a record bypasses the table
+
+__global__ __launch_bounds__(TPB) void boundary_records_kernel(const int* __restrict__ ids, Dims d, const int* __restrict__ halo_lo,
+                                                               const int* __restrict__ halo_hi, BoundaryRec* recs, unsigned* count, unsigned cap,
+                                                               size_t per_block) {
+    __shared__ int hkey[RH][7];
+    __shared__ unsigned htag[RH];
+    __shared__ int hcnt[RH];
+    __shared__ int any_flag[3];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < RH; i += TPB) {
+        htag[i] = 0u;
+        hcnt[i] = 0;
+    }
+    if (tid < 3) any_flag[tid] = 0;
+    __syncthreads();
     const size_t nvox = d.nvox();
     const size_t HW = (size_t)d.H * d.W;
-    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x) {
-        const int a = ids[v];
-        if (!a) continue;
-        const int x = (int)(v % d.W), y = (int)((v / d.W) % d.H), z = (int)(v / HW);
-        int nb[6];
-        int k = 0;
-        auto add = [&](int b) {
-            if (b == 0 || b == a) return;
-            for (int i = 0; i < k; ++i)
-                if (nb[i] == b) return;
-            nb[k++] = b;
-        };
-        if (x > 0) add(ids[v - 1]);
-        if (x + 1 < d.W) add(ids[v + 1]);
-        if (y > 0) add(ids[v - d.W]);
-        if (y + 1 < d.H) add(ids[v + d.W]);
-        if (z > 0) add(ids[v - HW]);
-        if (z + 1 < d.N) add(ids[v + HW]);
-        if (k) {
-            const unsigned slot = atomicAdd(count, 1u);
-            if (slot < cap) {
+    const size_t v0 = (size_t)blockIdx.x * per_block;
+    const size_t v1 = v0 + per_block < nvox ? v0 + per_block : nvox;
+    int tile = 0;
+    for (size_t base = v0; base < v1; base += TPB, ++tile) {  // block-uniform trip count
+        const size_t v = base + tid;
+        int a = 0;
+        int nb[6] = {0, 0, 0, 0, 0, 0};  // descending, distinct, zero padded
+        if (v < v1) a = ids[v];
+        if (a) {
+            const int x = (int)(v % d.W), y = (int)((v / d.W) % d.H), z = (int)(v / HW);
+            auto add = [&](int b) {
+                if (b == 0 || b == a) return;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    if (b == nb[i]) return;
+                    if (b > nb[i]) {
+                        const int t = nb[i];
+                        nb[i] = b;
+                        b = t;
+                        if (b == 0) return;
+                    }
+                }
+            };
+            if (x > 0) add(ids[v - 1]);
+            if (x + 1 < d.W) add(ids[v + 1]);
+            if (y > 0) add(ids[v - d.W]);
+            if (y + 1 < d.H) add(ids[v + d.W]);
+            if (z > 0) add(ids[v - HW]);
+            else if (halo_lo) { const int h = halo_lo[v]; add(h ? (h | HALO_LO) : 0); }
+            if (z + 1 < d.N) add(ids[v + HW]);
+            else if (halo_hi) { const int h = halo_hi[v - (size_t)z * HW]; add(h ? (h | HALO_HI) : 0); }
+        }
+        bool active = a != 0 && nb[0] != 0;
+        // does any thread of the workgroup hold a record in this tile?  (three flags in rotation: the one being
+        // cleared was last read two barriers ago)
+        const int f = tile % 3;
+        if (tid == 0) any_flag[(tile + 1) % 3] = 0;
+        if (active) any_flag[f] = 1;
+        __syncthreads();
+        if (!any_flag[f]) continue;
+        unsigned h = (unsigned)a * 0x9E3779B1u;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) h = (h ^ (unsigned)nb[i]) * 0x85EBCA77u + (h >> 15);
+        const unsigned tagv = h | 0x80000000u;
+        int slot = (int)((h >> 7) & (RH - 1));
+        for (int round = 0; round < RROUNDS; ++round) {  // block-uniform
+            int state = 0;                               // 1: wrote the key of `slot`, 2: must compare with the key of `slot`
+            if (active) {
+                const unsigned old = atomicCAS(&htag[slot], 0u, tagv);
+                if (old == 0u) {
+                    hkey[slot][0] = a;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) hkey[slot][1 + i] = nb[i];
+                    state = 1;
+                } else if (old == tagv) {
+                    state = 2;
+                } else {
+                    slot = (slot + 1) & (RH - 1);
+                }
+            }
+            __syncthreads();
+            if (state == 2) {
+                bool same = hkey[slot][0] == a;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) same = same && hkey[slot][1 + i] == nb[i];
+                if (same) state = 1;
+                else slot = (slot + 1) & (RH - 1);
+            }
+            if (state == 1) {
+                atomicAdd(&hcnt[slot], 1);
+                active = false;
+            }
+        }
+        if (active) {  // table crowded around this hash: the record leaves on its own
+            const unsigned o = atomicAdd(count, 1u);
+            if (o < cap) {
                 BoundaryRec r;
                 r.atom = a;
-                for (int i = 0; i < 6; ++i) r.nb[i] = i < k ? nb[i] : 0;
-                recs[slot] = r;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) r.nb[i] = nb[i];
+                r.count = 1;
+                recs[o] = r;
             }
+        }
+    }
+    __syncthreads();
+    for (int sl = tid; sl < RH; sl += TPB) {
+        if (htag[sl] == 0u || hcnt[sl] == 0) continue;
+        const unsigned o = atomicAdd(count, 1u);
+        if (o < cap) {
+            BoundaryRec r;
+            r.atom = hkey[sl][0];
+            for (int i = 0; i < 6; ++i) r.nb[i] = hkey[sl][1 + i];
+            r.count = hcnt[sl];
+            recs[o] = r;
         }
     }
 }
@@ -331,6 +421,70 @@ __global__ __launch_bounds__(TPB) void fill_write_kernel(const int* __restrict__
     }
 }
 
+// ---- slab-sharded mode --------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void atom_first_kernel(const int* __restrict__ P, const int* __restrict__ rank, int* first, int voxel_base, size_t nvox) {
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x)
+        if (P[v] == (int)v) first[rank[v]] = voxel_base + (int)v;
+}
+
+__global__ __launch_bounds__(TPB) void atom_face_flags_kernel(const int* __restrict__ ids, Dims d, bool zlo_face, bool zhi_face, int* flags) {
+    const size_t nvox = d.nvox();
+    const size_t HW = (size_t)d.H * d.W;
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(v % d.W), y = (int)((v / d.W) % d.H), z = (int)(v / HW);
+        if (x == 0 || y == 0 || x == d.W - 1 || y == d.H - 1 || (zlo_face && z == 0) || (zhi_face && z == d.N - 1)) {
+            const int a = ids[v];
+            if (a) flags[a] = 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(TPB) void face_edges_kernel(const int* __restrict__ ids_a, const int* __restrict__ lab_a, const int* __restrict__ ids_b,
+                                                         const int* __restrict__ lab_b, int H, int W, bool conn26, int* edges, unsigned* count,
+                                                         unsigned cap) {
+    const size_t HW = (size_t)H * W;
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < HW; v += (size_t)gridDim.x * blockDim.x) {
+        const int a = ids_a[v];
+        if (!a) continue;
+        const int x = (int)(v % W), y = (int)(v / W);
+        const int la = lab_a ? lab_a[v] : 1;
+        const int a_left = x > 0 ? ids_a[v - 1] : 0;
+        const int r = conn26 ? 1 : 0;
+        for (int dy = -r; dy <= r; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= H) continue;
+            for (int dx = -r; dx <= r; ++dx) {
+                const int xx = x + dx;
+                if (xx < 0 || xx >= W) continue;
+                const size_t u = (size_t)yy * W + xx;
+                const int b = ids_b[u];
+                if (!b || (lab_b && lab_b[u] != la)) continue;
+                if (a_left == a && xx > 0 && ids_b[u - 1] == b) continue;  // the voxel to the left emits the same pair
+                const unsigned slot = atomicAdd(count, 1u);
+                if (slot < cap) {
+                    edges[2 * (size_t)slot] = a;
+                    edges[2 * (size_t)slot + 1] = b;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(TPB) void widen_u8_kernel(const uint8_t* __restrict__ in, int* __restrict__ out, size_t n) {
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (size_t)gridDim.x * blockDim.x) out[v] = in[v];
+}
+
+__global__ __launch_bounds__(TPB) void lut_complement_kernel(const int* __restrict__ ids, const uint8_t* __restrict__ keeplut, uint8_t label,
+                                                             uint8_t* __restrict__ bg, size_t nvox) {
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x) bg[v] = keeplut[ids[v]] != label ? 1 : 0;
+}
+
+__global__ __launch_bounds__(TPB) void fill_write_lut_kernel(const int* __restrict__ ids2, const uint8_t* __restrict__ keeplut, const int* __restrict__ ids3,
+                                                             const uint8_t* __restrict__ holelut, uint8_t label, uint8_t* out, size_t nvox) {
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x)
+        if (keeplut[ids2[v]] == label || holelut[ids3[v]]) out[v] = label;
+}
+
 __global__ __launch_bounds__(TPB) void volume_max_kernel(const uint8_t* __restrict__ a, unsigned* mx, size_t nvox) {
     unsigned m = 0;
     for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x) m = max(m, (unsigned)a[v]);
@@ -379,7 +533,50 @@ hipError_t region_stats(const int* ids, const uint8_t* lab, int* area, uint8_t* 
 }
 
 hipError_t boundary_records(const int* ids, Dims d, BoundaryRec* recs, unsigned* count_dev, unsigned cap, hipStream_t s) {
-    LM_LAUNCH(boundary_records_kernel, dim3(grid_for(d.nvox())), dim3(TPB), 0, s, ids, d, recs, count_dev, cap);
+    return boundary_records_halo(ids, d, nullptr, nullptr, recs, count_dev, cap, s);
+}
+
+hipError_t boundary_records_halo(const int* ids, Dims d, const int* halo_lo, const int* halo_hi, BoundaryRec* recs, unsigned* count_dev,
+                                 unsigned cap, hipStream_t s) {
+    const size_t nvox = d.nvox();
+    if (nvox == 0) return hipSuccess;
+    // contiguous ranges of >= 8 tiles per workgroup (the longer the range, the more voxels share a table)
+    size_t per = (nvox + 2047) / 2048;
+    per = std::max<size_t>((per + TPB - 1) / TPB * TPB, 8 * TPB);
+    const unsigned blocks = (unsigned)((nvox + per - 1) / per);
+    LM_LAUNCH(boundary_records_kernel, dim3(blocks), dim3(TPB), 0, s, ids, d, halo_lo, halo_hi, recs, count_dev, cap, per);
+    return hipGetLastError();
+}
+
+hipError_t atom_first(const int* parent, const int* rank, int* first, int voxel_base, size_t nvox, hipStream_t s) {
+    LM_LAUNCH(atom_first_kernel, dim3(grid_for(nvox)), dim3(TPB), 0, s, parent, rank, first, voxel_base, nvox);
+    return hipGetLastError();
+}
+
+hipError_t atom_face_flags(const int* ids, Dims d, bool zlo_face, bool zhi_face, int* flags, hipStream_t s) {
+    LM_LAUNCH(atom_face_flags_kernel, dim3(grid_for(d.nvox())), dim3(TPB), 0, s, ids, d, zlo_face, zhi_face, flags);
+    return hipGetLastError();
+}
+
+hipError_t face_edges(const int* ids_a, const int* lab_a, const int* ids_b, const int* lab_b, int H, int W, bool conn26, int* edges,
+                      unsigned* count_dev, unsigned cap, hipStream_t s) {
+    LM_LAUNCH(face_edges_kernel, dim3(grid_for((size_t)H * W)), dim3(TPB), 0, s, ids_a, lab_a, ids_b, lab_b, H, W, conn26, edges, count_dev, cap);
+    return hipGetLastError();
+}
+
+hipError_t widen_u8(const uint8_t* in, int* out, size_t n, hipStream_t s) {
+    LM_LAUNCH(widen_u8_kernel, dim3(grid_for(n)), dim3(TPB), 0, s, in, out, n);
+    return hipGetLastError();
+}
+
+hipError_t lut_complement(const int* ids, const uint8_t* keeplut, uint8_t label, uint8_t* bg, size_t nvox, hipStream_t s) {
+    LM_LAUNCH(lut_complement_kernel, dim3(grid_for(nvox)), dim3(TPB), 0, s, ids, keeplut, label, bg, nvox);
+    return hipGetLastError();
+}
+
+hipError_t fill_write_lut(const int* ids2, const uint8_t* keeplut, const int* ids3, const uint8_t* holelut, uint8_t label, uint8_t* out,
+                          size_t nvox, hipStream_t s) {
+    LM_LAUNCH(fill_write_lut_kernel, dim3(grid_for(nvox)), dim3(TPB), 0, s, ids2, keeplut, ids3, holelut, label, out, nvox);
     return hipGetLastError();
 }
 

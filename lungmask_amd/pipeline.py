@@ -4,12 +4,18 @@
 Sharding: pre-processing, the network forward and the argmax are
 slice-wise (utils.py:48-51, mask.py:173-187) -> contiguous slice blocks per rank,
 weights replicated, NO collective.  The 3-D post-processing (utils.py:272-358) spans
-the whole volume -> ONE all-gather of the uint8 256x256 label shards (64 KiB/slice);
-every rank then runs the identical deterministic post-processing, un-crops its own
-slices, and a second all-gather assembles the [n,h,w] result on every rank.  xGMI is
-point-to-point and fully connected inside a node, so both all-gathers are single-step
-and per-link bound (shard_bytes / ~153 GB/s): 19.7 MB + 78.6 MB per rank at 300
-slices/rank, well under a millisecond each.
+the whole volume; two forms:
+
+* slab-sharded (default): every rank post-processes its own slab and the slabs are tied
+  together by six small all-gathers of face planes / atom tables (`lm_slab_*`,
+  csrc/slab_engine.hip) -- the voxel passes scale with 1/world;
+* gathered (`sharded_post=False`, and whenever a rank has no slice): ONE all-gather of the
+  uint8 256x256 label shards (64 KiB/slice), then every rank runs the identical
+  deterministic whole-volume post-processing (the serial fraction of weak scaling).
+
+Each rank then un-crops its own slices and a final all-gather assembles the [n,h,w]
+result on every rank (79 MB per rank at 300 slices/rank; xGMI is point-to-point and fully
+connected inside a node, so it is single-step and per-link bound, well under a millisecond).
 
 All buffers are torch tensors (device memory + collectives are torch's job here,
 nothing else); the engine receives raw pointers.  In the CPU test-suite the tensors
@@ -17,6 +23,7 @@ are host tensors, the backend is gloo and the engine is the test emulation.
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import List, Sequence
 
 import numpy as np
@@ -37,7 +44,7 @@ class ShardedPipeline:
     device: torch device that matches the engine's memory space ('cuda:<i>' or 'cpu' under emulation)."""
 
     def __init__(self, engine, slot: int = 0, batch_size: int = 20, volume_postprocessing: bool = True,
-                 resolution: Sequence[int] = (256, 256), dist=None, device="cpu"):
+                 resolution: Sequence[int] = (256, 256), dist=None, device="cpu", sharded_post: bool = True):
         self.e = engine
         self.slot = slot
         self.batch_size = int(batch_size)
@@ -47,6 +54,7 @@ class ShardedPipeline:
         self.device = torch.device(device)
         self.world = dist.get_world_size() if dist is not None else 1
         self.rank = dist.get_rank() if dist is not None else 0
+        self.sharded_post = bool(sharded_post)
         self._buf = {}
 
     def _tensor(self, key, shape, dtype):
@@ -61,52 +69,140 @@ class ShardedPipeline:
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
 
+    def _all_gather(self, out: torch.Tensor, mine: torch.Tensor):
+        # gloo must not alias input and output; RCCL gathers in place
+        self.dist.all_gather_into_tensor(out, mine.clone() if self.device.type == "cpu" else mine)
+        self._sync_torch()
+
+    def postprocess_slab(self, lab_slab: torch.Tensor, z0: int, n_total: int, spare: Sequence[int] = (), skip_below: int = 3):
+        """utils.postprocessing over a volume whose slices are spread over the ranks; `lab_slab` (uint8 [n_r,h,w], n_r >= 1,
+        slices [z0, z0+n_r)) is processed IN PLACE.  Protocol of include/lungmask_hip.h (lm_slab_*)."""
+        e, lib = self.e, self.e.L.lib
+        n_r, h, w = (int(v) for v in lab_slab.shape)
+        sp = (C.c_int * max(len(spare), 1))(*[int(v) for v in spare])
+        e.L.check(lib.lm_slab_begin(e.h, lab_slab.data_ptr(), n_r, h, w, self.rank, self.world, int(z0), int(n_total), sp, len(spare), int(skip_below)),
+                  "lm_slab_begin")
+        while True:
+            n = int(lib.lm_slab_pending(e.h))
+            if n < 0:
+                raise RuntimeError("lm_slab_pending: no slab post-processing in progress")
+            if self.world > 1:
+                lens_t = self._tensor("slab_lens", (self.world,), torch.int64)
+                self._all_gather(lens_t, torch.tensor([n], dtype=torch.int64, device=self.device))
+                lens = [int(v) for v in lens_t.cpu().tolist()]
+            else:
+                lens = [n]
+            stride = max(lens)
+            mine = self._tensor("slab_mine", (max(stride, 1),), torch.int32)
+            gathered = self._tensor("slab_all", (self.world * max(stride, 1),), torch.int32) if self.world > 1 else mine
+            e.L.check(lib.lm_slab_emit(e.h, mine.data_ptr()), "lm_slab_emit")
+            if stride and self.world > 1:
+                self._all_gather(gathered, mine)
+            status = e.L.check(lib.lm_slab_step(e.h, gathered.data_ptr(), stride, (C.c_int64 * self.world)(*lens)), "lm_slab_step")
+            if status == 1:
+                return
+
+    def shard_buffers(self, n_total: int):
+        """(bounds, bbox [maxc,4] int32, lab_all [world*maxc,oh,ow] u8, lab_loc = this rank's part of lab_all)."""
+        bounds = shard_bounds(n_total, self.world)
+        maxc = max(bounds[r + 1] - bounds[r] for r in range(self.world))
+        oh, ow = self.res
+        bbox = self._tensor("bbox", (maxc, 4), torch.int32)
+        lab_all = self._tensor("lab_all", (self.world * maxc, oh, ow), torch.uint8)
+        lab_loc = lab_all[self.rank * maxc : (self.rank + 1) * maxc] if self.world > 1 else lab_all
+        return bounds, bbox, lab_all, lab_loc
+
     def apply_shard(self, vol_shard: torch.Tensor, n_total: int) -> torch.Tensor:
         """vol_shard: this rank's contiguous slice block [n_r,h,w] int16, resident in the engine's memory
         space.  Returns the FULL uint8 label volume [n_total,h,w] (same memory space)."""
         e, lib = self.e, self.e.L.lib
         n_r, h, w = (int(s) for s in vol_shard.shape)
-        bounds = shard_bounds(n_total, self.world)
-        counts = [bounds[r + 1] - bounds[r] for r in range(self.world)]
-        assert n_r == counts[self.rank], (n_r, counts, self.rank)
+        bounds, bbox, _, lab_loc = self.shard_buffers(n_total)
+        assert n_r == bounds[self.rank + 1] - bounds[self.rank], (n_r, bounds, self.rank)
         assert vol_shard.dtype == torch.int16 and vol_shard.is_contiguous()
-        maxc = max(counts)
         oh, ow = self.res
-        bbox = self._tensor("bbox", (maxc, 4), torch.int32)
-        xf = self._tensor("xf", (maxc, oh, ow), torch.float32)
-        lab_all = self._tensor("lab_all", (self.world * maxc, oh, ow), torch.uint8)
-        lab_loc = lab_all[self.rank * maxc : (self.rank + 1) * maxc] if self.world > 1 else lab_all
+        xf = self._tensor("xf", (max(n_r, 1), oh, ow), torch.float32)
         self._sync_torch()
         # ---- sliced stages: no communication
         if n_r:
             e.L.check(lib.lm_preprocess_dev(e.h, vol_shard.data_ptr(), 0, n_r, h, w, oh, ow, bbox.data_ptr(), xf.data_ptr(), None, None), "lm_preprocess_dev")
             e.L.check(lib.lm_forward_batches_dev(e.h, self.slot, xf.data_ptr(), n_r, oh, ow, self.batch_size, lab_loc.data_ptr()), "lm_forward_batches_dev")
         e.sync()
-        # ---- exchange #1: 256^2 label shards -> whole label volume on every rank (RCCL all-gather, in place)
-        if self.world > 1:
-            self.dist.all_gather_into_tensor(lab_all.view(-1), lab_loc.reshape(-1).clone() if self.device.type == "cpu" else lab_loc.reshape(-1))
-            self._sync_torch()
-            if any(c != maxc for c in counts):  # ragged tail: compact the padded shards
-                full = torch.cat([lab_all[r * maxc : r * maxc + counts[r]] for r in range(self.world)]).contiguous()
-            else:
-                full = lab_all
+        return self.assemble(n_total, h, w)
+
+    def assemble(self, n_total: int, h: int, w: int) -> torch.Tensor:
+        """Everything after the argmax: volume post-processing of the label shards in `shard_buffers(n_total)`, un-crop with
+        the shard's bounding boxes, and the all-gather of the [n_total,h,w] result."""
+        e, lib = self.e, self.e.L.lib
+        bounds, bbox, lab_all, lab_loc = self.shard_buffers(n_total)
+        counts = [bounds[r + 1] - bounds[r] for r in range(self.world)]
+        n_r, maxc = counts[self.rank], max(counts)
+        oh, ow = self.res
+        slabs = self.sharded_post and self.world > 1 and min(counts) >= 1 and n_total > 1
+        if slabs:
+            # ---- post-processing on the own slab; six small exchanges inside (no label all-gather at all)
+            mine_lab = lab_loc[:n_r]
+            if self.volume_postprocessing:
+                self.postprocess_slab(mine_lab, bounds[self.rank], n_total)
         else:
-            full = lab_all[:n_r]
-        self._sync_torch()
-        if self.volume_postprocessing and n_total:
-            e.L.check(lib.lm_postprocess_dev(e.h, full.data_ptr(), n_total, oh, ow, None, 0, 3), "lm_postprocess_dev")
+            # ---- exchange #1: 256^2 label shards -> whole label volume on every rank (RCCL all-gather, in place)
+            if self.world > 1:
+                self._all_gather(lab_all.view(-1), lab_loc.reshape(-1))
+                if any(c != maxc for c in counts):  # ragged tail: compact the padded shards
+                    full = torch.cat([lab_all[r * maxc : r * maxc + counts[r]] for r in range(self.world)]).contiguous()
+                else:
+                    full = lab_all
+            else:
+                full = lab_all[:n_r]
+            self._sync_torch()
+            if self.volume_postprocessing and n_total:
+                e.L.check(lib.lm_postprocess_dev(e.h, full.data_ptr(), n_total, oh, ow, None, 0, 3), "lm_postprocess_dev")
+            mine_lab = full[bounds[self.rank] : bounds[self.rank + 1]]
         # ---- un-crop own slices
         out_all = self._tensor("out_all", (self.world * maxc, h, w), torch.uint8)
         out_loc = out_all[self.rank * maxc : (self.rank + 1) * maxc] if self.world > 1 else out_all
         if n_r:
-            mine = full[bounds[self.rank] : bounds[self.rank + 1]]
-            e.L.check(lib.lm_reshape_mask_dev(e.h, mine.data_ptr(), bbox.data_ptr(), n_r, oh, ow, h, w, out_loc.data_ptr()), "lm_reshape_mask_dev")
+            e.L.check(lib.lm_reshape_mask_dev(e.h, mine_lab.data_ptr(), bbox.data_ptr(), n_r, oh, ow, h, w, out_loc.data_ptr()), "lm_reshape_mask_dev")
         e.sync()
         # ---- exchange #2: output shards
         if self.world > 1:
-            self.dist.all_gather_into_tensor(out_all.view(-1), out_loc.reshape(-1).clone() if self.device.type == "cpu" else out_loc.reshape(-1))
-            self._sync_torch()
+            self._all_gather(out_all.view(-1), out_loc.reshape(-1))
             if any(c != maxc for c in counts):
                 return torch.cat([out_all[r * maxc : r * maxc + counts[r]] for r in range(self.world)]).contiguous()
             return out_all
         return out_all[:n_r]
+
+
+def postprocess_slabs_in_process(engines, lab: np.ndarray, bounds: Sequence[int], spare: Sequence[int] = (), skip_below: int = 3) -> np.ndarray:
+    """The lm_slab_* protocol with every "rank" in THIS process: engines[r] (all on one device / memory space) owns slices
+    [bounds[r], bounds[r+1]) of `lab`; the exchanges are plain device copies.  Used to exercise the multi-rank code on
+    one GPU (tests) -- same calls, same tables, no torch.distributed."""
+    world = len(engines)
+    assert len(bounds) == world + 1 and all(bounds[r + 1] > bounds[r] for r in range(world))
+    n_total, h, w = lab.shape
+    sp = (C.c_int * max(len(spare), 1))(*[int(v) for v in spare])
+    slabs = []
+    for r, e in enumerate(engines):
+        d = e.to_device(np.ascontiguousarray(lab[bounds[r] : bounds[r + 1]], dtype=np.uint8))
+        slabs.append(d)
+        e.L.check(e.L.lib.lm_slab_begin(e.h, d.ptr, bounds[r + 1] - bounds[r], h, w, r, world, bounds[r], n_total, sp, len(spare), int(skip_below)),
+                  "lm_slab_begin")
+    rounds = 0
+    while True:
+        lens = [int(e.L.lib.lm_slab_pending(e.h)) for e in engines]
+        assert min(lens) >= 0
+        stride = max(lens)
+        gathered = engines[0].empty((world * max(stride, 1),), np.int32)
+        for r, e in enumerate(engines):
+            e.L.check(e.L.lib.lm_slab_emit(e.h, gathered.ptr + 4 * r * stride), "lm_slab_emit")
+        status = [e.L.check(e.L.lib.lm_slab_step(e.h, gathered.ptr, stride, (C.c_int64 * world)(*lens)), "lm_slab_step") for e in engines]
+        gathered.free()
+        rounds += 1
+        assert len(set(status)) == 1, status
+        if status[0] == 1:
+            break
+    assert rounds == 6, rounds
+    out = np.concatenate([d.download() for d in slabs])
+    for d in slabs:
+        d.free()
+    return out

@@ -111,3 +111,63 @@ def check_reorient(engine):
                 assert np.array_equal(got, vio.apply_transform(a, axes, flips)), (dt, axes, flips)
                 assert np.array_equal(vio.apply_transform(got, *vio.inverse_transform(axes, flips)), a)
         d.free()
+
+
+def check_slab_postprocess(engines, shapes=((9, 24, 20), (5, 16, 16)), seeds=range(3), golden_max_voxels=40000):
+    """Slab-sharded post-processing (lm_slab_*, csrc/slab_engine.hip) with 1..len(engines) in-process ranks and every kind of
+    cut (ragged, one-slice slabs) == the oracle == the whole-volume path.  Also the reference-generated goldens."""
+    from lungmask_amd.pipeline import postprocess_slabs_in_process, shard_bounds
+    from oracle.make_golden import random_blobs
+
+    n_checked = 0
+    for shape in shapes:
+        for seed in seeds:
+            rng = np.random.default_rng(100 + seed)
+            nlab = 4
+            lab = random_blobs(rng, shape, nlab, 10, 0.3)
+            for spare, skip in (((), 3), ((nlab,), 3), ((), 1)):
+                ref = po.postprocessing(lab.copy(), spare=list(spare), skip_below=skip)
+                for world in range(1, len(engines) + 1):
+                    cuts = [shard_bounds(shape[0], world)]
+                    if world == 2:
+                        cuts += [[0, 1, shape[0]], [0, shape[0] - 1, shape[0]]]
+                    if world == 3:
+                        cuts += [[0, 1, 2, shape[0]]]
+                    for b in cuts:
+                        out = postprocess_slabs_in_process(engines[:world], lab, b, spare, skip)
+                        assert np.array_equal(out, ref), (shape, seed, spare, skip, b, int((out != ref).sum()))
+                        n_checked += 1
+    # salt-and-pepper volumes: thousands of tiny regions, most boundary records cross a slab face
+    for seed in seeds:
+        rng = np.random.default_rng(200 + seed)
+        lab = rng.integers(0, 4, (6, 14, 12)).astype(np.uint8)
+        lab[rng.random(lab.shape) < 0.35] = 0
+        ref = po.postprocessing(lab.copy())
+        for world in range(2, len(engines) + 1):
+            out = postprocess_slabs_in_process(engines[:world], lab, shard_bounds(6, world))
+            assert np.array_equal(out, ref), (seed, world, int((out != ref).sum()))
+            n_checked += 1
+    # a hollow shell cut by the slab faces: the cavity is a hole only when all its slab pieces are enclosed
+    lab = np.zeros((8, 12, 12), np.uint8)
+    lab[1:7, 2:10, 2:10] = 1
+    lab[2:6, 4:8, 4:8] = 0
+    lab2 = lab.copy()
+    lab2[4, 5, 2:5] = 0  # a tunnel from the cavity to the outside, inside ONE slab
+    for v in (lab, lab2):
+        ref = po.postprocessing(v.copy())
+        for world in range(2, len(engines) + 1):
+            out = postprocess_slabs_in_process(engines[:world], v, shard_bounds(8, world))
+            assert np.array_equal(out, ref), (world, int((out != ref).sum()))
+            n_checked += 1
+    assert po.postprocessing(lab.copy())[3, 5, 5] == 1 and po.postprocessing(lab2.copy())[3, 5, 5] == 0
+    g = np.load(GOLD)
+    for i in range(int(g["n_post"])):
+        lab = g[f"post{i}_lab"]
+        if lab.shape[0] < 2 or lab.size > golden_max_voxels:
+            continue
+        spare = [int(x) for x in g[f"post{i}_spare"]]
+        world = min(len(engines), lab.shape[0])
+        out = postprocess_slabs_in_process(engines[:world], lab, shard_bounds(lab.shape[0], world), spare, int(g[f"post{i}_skip"]))
+        assert np.array_equal(out, g[f"post{i}_out"]), (i, lab.shape, spare)
+        n_checked += 1
+    return n_checked

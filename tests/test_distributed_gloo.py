@@ -22,7 +22,19 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_total, outdir):
+def _labels_and_boxes(n_total, res, hw, seed=7):
+    """A structured label volume (components crossing the slab faces) + per-slice bounding boxes for the un-crop."""
+    from oracle.make_golden import random_blobs
+
+    rng = np.random.default_rng(seed)
+    lab = random_blobs(rng, (n_total, res, res), 4, 10, 0.3)
+    r0 = rng.integers(0, hw[0] // 3, n_total)
+    c0 = rng.integers(0, hw[1] // 3, n_total)
+    boxes = np.stack([r0, c0, r0 + rng.integers(8, hw[0] // 2, n_total), c0 + rng.integers(8, hw[1] // 2, n_total)], axis=1).astype(np.int32)
+    return lab, boxes
+
+
+def _worker(rank, world, port, n_total, outdir, mode):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="4")
     import torch.distributed as dist
@@ -35,13 +47,26 @@ def _worker(rank, world, port, n_total, outdir):
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     eng = nat.Engine(0, nat.Library(build_emu(), allow_emulation=True))
-    eng.load_state_dict(0, uo.synthetic_state_dict(3))
-    vol = po.phantom(n_total, 96, 80, seed=3)
     b = shard_bounds(n_total, world)
-    shard = torch.from_numpy(vol[b[rank] : b[rank + 1]].copy())
-    pipe = ShardedPipeline(eng, slot=0, batch_size=2, resolution=(32, 32), dist=dist, device="cpu")
-    out = pipe.apply_shard(shard, n_total).numpy().copy()
-    np.save(os.path.join(outdir, f"out{rank}.npy"), out)
+    if mode == "full":  # the whole sharded pipeline incl. the (emulated, slow) network
+        eng.load_state_dict(0, uo.synthetic_state_dict(3))
+        vol = po.phantom(n_total, 96, 80, seed=3)
+        shard = torch.from_numpy(vol[b[rank] : b[rank + 1]].copy())
+        pipe = ShardedPipeline(eng, slot=0, batch_size=2, resolution=(32, 32), dist=dist, device="cpu")
+        np.save(os.path.join(outdir, f"out{rank}.npy"), pipe.apply_shard(shard, n_total).numpy().copy())
+    else:  # everything after the argmax, on a structured label volume, in both post-processing forms
+        lab, boxes = _labels_and_boxes(n_total, 32, (96, 80))
+        for sharded in (True, False):
+            pipe = ShardedPipeline(eng, resolution=(32, 32), dist=dist, device="cpu", sharded_post=sharded)
+            _, bbox, _, lab_loc = pipe.shard_buffers(n_total)
+            n_r = b[rank + 1] - b[rank]
+            lab_loc[:n_r] = torch.from_numpy(lab[b[rank] : b[rank + 1]])
+            bbox[:n_r] = torch.from_numpy(boxes[b[rank] : b[rank + 1]])
+            np.save(os.path.join(outdir, f"asm{int(sharded)}_{rank}.npy"), pipe.assemble(n_total, 96, 80).numpy().copy())
+        # the exchange protocol with a fusion-style spare label
+        slab = torch.from_numpy(lab[b[rank] : b[rank + 1]].copy())
+        pipe.postprocess_slab(slab, b[rank], n_total, spare=(4,))
+        np.save(os.path.join(outdir, f"slab{rank}.npy"), slab.numpy())
     dist.barrier()
     dist.destroy_process_group()
     eng.close()
@@ -56,18 +81,17 @@ def test_shard_bounds():
 
 
 @pytest.mark.slow
-def test_two_rank_gloo_matches_single_rank(emu_engine, tmp_path):
+def test_two_rank_gloo_full_pipeline_matches_single_rank(emu_engine, tmp_path):
+    """Ragged shards (2 + 1 slices) through pre-processing, the network, the slab-sharded post-processing and both gathers."""
     from lungmask_amd.build import build_emu
     from lungmask_amd.pipeline import ShardedPipeline
     from oracle import prepost_oracle as po
     from oracle import unet_oracle as uo
 
     build_emu()
-    n_total = 3  # ragged: rank 0 gets 2 slices, rank 1 gets 1
-    port = _free_port()
-    mp.spawn(_worker, args=(2, port, n_total, str(tmp_path)), nprocs=2, join=True)
-    out0 = np.load(tmp_path / "out0.npy")
-    out1 = np.load(tmp_path / "out1.npy")
+    n_total, world = 3, 2
+    mp.spawn(_worker, args=(world, _free_port(), n_total, str(tmp_path), "full"), nprocs=world, join=True)
+    out0, out1 = np.load(tmp_path / "out0.npy"), np.load(tmp_path / "out1.npy")
     assert out0.shape == (n_total, 96, 80) and np.array_equal(out0, out1)  # every rank holds the full result
     # single-rank reference through the same stage calls
     emu_engine.load_state_dict(0, uo.synthetic_state_dict(3))
@@ -80,3 +104,22 @@ def test_two_rank_gloo_matches_single_rank(emu_engine, tmp_path):
     post = po.postprocessing(lab.copy())
     expect = np.asarray([po.reshape_mask(post[i], boxes[i], vol.shape[1:]) for i in range(n_total)], dtype=np.uint8)
     assert np.array_equal(single, expect)
+
+
+@pytest.mark.parametrize("world,n_total", [(2, 5), (3, 7), (4, 4)])
+def test_multi_rank_gloo_assemble_and_slab_protocol(tmp_path, world, n_total):
+    """Everything after the argmax with 2-4 ranks over gloo: slab-sharded and gathered post-processing agree with the oracle
+    (utils.postprocessing + utils.reshape_mask) on a label volume whose components cross the slab faces."""
+    from lungmask_amd.build import build_emu
+    from oracle import prepost_oracle as po
+
+    build_emu()
+    mp.spawn(_worker, args=(world, _free_port(), n_total, str(tmp_path), "post"), nprocs=world, join=True)
+    lab, boxes = _labels_and_boxes(n_total, 32, (96, 80))
+    post = po.postprocessing(lab.copy())
+    expect = np.asarray([po.reshape_mask(post[i], boxes[i], (96, 80)) for i in range(n_total)], dtype=np.uint8)
+    for sharded in (0, 1):
+        for r in range(world):
+            assert np.array_equal(np.load(tmp_path / f"asm{sharded}_{r}.npy"), expect), (sharded, r)
+    got = np.concatenate([np.load(tmp_path / f"slab{r}.npy") for r in range(world)])
+    assert np.array_equal(got, po.postprocessing(lab.copy(), spare=[4]))

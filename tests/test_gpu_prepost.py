@@ -70,3 +70,40 @@ def test_postprocess_idempotent_and_deterministic_large(gpu_engine):
     assert np.array_equal(a, c)  # one component per label without holes is a fixed point
     for v in np.unique(a)[1:]:
         assert po.sk_label(a == v).max() == 1
+
+
+def test_slab_sharded_postprocessing(gpu_engine):
+    """lm_slab_* with 1-4 in-process ranks (separate engines on the one GPU): small structured cases against the oracle."""
+    from lungmask_amd import _native as nat
+
+    extra = [nat.Engine(0) for _ in range(3)]
+    try:
+        assert cases.check_slab_postprocess([gpu_engine] + extra) >= 60
+    finally:
+        for e in extra:
+            e.close()
+
+
+def test_slab_sharded_postprocessing_full_size(gpu_engine):
+    """A 120 x 256 x 256 label volume as the network produces it on the phantom (noisy: ~10^4 regions, ~10^5 boundary
+    records), cut into 4 and 8 slabs (ragged): bit-identical to the whole-volume path, which the other tests pin to the oracle."""
+    from lungmask_amd import _native as nat
+    from lungmask_amd.pipeline import postprocess_slabs_in_process, shard_bounds
+    from oracle import unet_oracle as uo
+
+    gpu_engine.load_state_dict(0, uo.synthetic_state_dict(3))
+    vol = po.phantom(120, 512, 512, seed=9)
+    xf = gpu_engine.preprocess(vol)[1]
+    lab = gpu_engine.forward(0, xf[:, None], want_logp=False)[0]
+    whole = gpu_engine.postprocess(lab)
+    info = gpu_engine.postprocess_info()
+    assert info["regions"] > 100 and (whole != lab).any()
+    extra = [nat.Engine(0) for _ in range(7)]
+    try:
+        engines = [gpu_engine] + extra
+        for world, bounds in ((4, shard_bounds(120, 4)), (8, shard_bounds(120, 8)), (3, [0, 1, 119, 120]), (7, shard_bounds(120, 7))):
+            out = postprocess_slabs_in_process(engines[:world], lab, bounds)
+            assert np.array_equal(out, whole), (world, int((out != whole).sum()))
+    finally:
+        for e in extra:
+            e.close()

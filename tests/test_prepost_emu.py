@@ -29,3 +29,15 @@ def test_fusion_emulated(emu_engine):
 
 def test_reorient_emulated(emu_engine):
     cases.check_reorient(emu_engine)
+
+
+def test_slab_sharded_postprocessing_emulated(emu_engine):
+    """The multi-GPU form of the post-processing with up to 4 in-process ranks on the emulator."""
+    from lungmask_amd import _native as nat
+
+    extra = [nat.Engine(0, emu_engine.L) for _ in range(3)]
+    try:
+        assert cases.check_slab_postprocess([emu_engine] + extra) >= 60
+    finally:
+        for e in extra:
+            e.close()
