@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=96)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="split_f16", choices=["split_f16", "f32"])
+    ap.add_argument("--post", default="slab", choices=["slab", "gathered"], help="N>1 post-processing: slab-sharded (default) or label all-gather + redundant whole-volume pass")
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2], help="forward lanes (2: consecutive batches overlap on two streams)")
     args = ap.parse_args()
 
@@ -102,10 +103,14 @@ def main():
     from oracle import unet_oracle as uo
 
     dist = None
-    if world > 1:
+    # LM_BENCH_FORCE_DIST=1: take the multi-GPU code path (RCCL process group, ShardedPipeline) with a world of one,
+    # which is how that path is smoke-tested on a 1-GPU box
+    use_dist = world > 1 or os.environ.get("LM_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
@@ -133,7 +138,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    if world == 1:
+    if not use_dist:
         vd = eng.to_device(vol)
         od = eng.empty(vol.shape, np.uint8)
 
@@ -144,7 +149,7 @@ def main():
 
         dev = torch.device("cuda", local_rank)
         vt = torch.from_numpy(vol).to(dev)
-        pipe = ShardedPipeline(eng, slot=0, batch_size=args.batch, dist=dist, device=dev)
+        pipe = ShardedPipeline(eng, slot=0, batch_size=args.batch, dist=dist, device=dev, sharded_post=args.post == "slab")
 
         def step():
             pipe.apply_shard(vt, n_total)
@@ -236,7 +241,7 @@ def main():
                 "workload": f"R231 U-Net, 512x512x{n_local} int16 HU phantom per GPU ({n_total} slices total), batchsize={args.batch}, "
                             "LMInferer.apply device-resident (pre + forward + argmax + 3-D post + un-crop)",
                 "weights": weights,
-                "parallelism": "single GPU" if world == 1 else f"slice-sharded x{world}, 2 RCCL all-gathers (labels, output)",
+                "parallelism": "single GPU" if not use_dist else (f"slice-sharded x{world}: slab-local post-processing + 6 small RCCL table all-gathers, 1 all-gather of the output" if args.post == "slab" else f"slice-sharded x{world}: RCCL all-gather of the labels, redundant whole-volume post-processing, all-gather of the output"),
             },
             "end_to_end_tflops": round(value * FLOP_PER_SLICE / 1e12, 2),
             "roofline": roof,
@@ -245,10 +250,18 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, sd)
-        print(json.dumps(out), flush=True)
+    # The JSON line must be the LAST line of the job's stdout: RCCL prints a version banner through C stdio, which is
+    # block-buffered on a pipe and would otherwise be flushed at exit, after Python's own output -- on every rank.
+    import ctypes
+
+    libc = ctypes.CDLL(None)
     if dist is not None:
+        libc.fflush(None)
         dist.barrier()
         dist.destroy_process_group()
+    libc.fflush(None)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -39,7 +39,21 @@ int lm_engine_create(lm_engine** out, int device_id) {
         delete e;
         return LM_ERR_DEVICE;
     }
-    if (hipStreamCreate(&e->stream2) != hipSuccess || hipEventCreate(&e->ev_fork) != hipSuccess || hipEventCreate(&e->ev_join) != hipSuccess) {
+    // The second forward lane must sit on a different hardware queue than the first, or the two batches serialise.
+    // Same-priority streams share a small round-robin pool of queues (whether two of them collide depends on how many
+    // streams the process created before -- e.g. torch.distributed's -- which cost 15 % in one start-up order); a stream of
+    // another priority class always gets a queue of its own.  Lowest priority: the lane fills gaps, it never preempts.
+    hipError_t err2;
+#ifndef LM_EMU_BUILD
+    {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        err2 = hipStreamCreateWithPriority(&e->stream2, hipStreamDefault, least);
+    }
+#else
+    err2 = hipStreamCreate(&e->stream2);
+#endif
+    if (err2 != hipSuccess || hipEventCreate(&e->ev_fork) != hipSuccess || hipEventCreate(&e->ev_join) != hipSuccess) {
         set_error("creating the second forward lane failed");
         e->stream2 = nullptr;
         e->n_streams = 1;

@@ -86,7 +86,7 @@ class ShardedPipeline:
             n = int(lib.lm_slab_pending(e.h))
             if n < 0:
                 raise RuntimeError("lm_slab_pending: no slab post-processing in progress")
-            if self.world > 1:
+            if self.dist is not None:
                 lens_t = self._tensor("slab_lens", (self.world,), torch.int64)
                 self._all_gather(lens_t, torch.tensor([n], dtype=torch.int64, device=self.device))
                 lens = [int(v) for v in lens_t.cpu().tolist()]
@@ -94,9 +94,9 @@ class ShardedPipeline:
                 lens = [n]
             stride = max(lens)
             mine = self._tensor("slab_mine", (max(stride, 1),), torch.int32)
-            gathered = self._tensor("slab_all", (self.world * max(stride, 1),), torch.int32) if self.world > 1 else mine
+            gathered = self._tensor("slab_all", (self.world * max(stride, 1),), torch.int32) if self.dist is not None else mine
             e.L.check(lib.lm_slab_emit(e.h, mine.data_ptr()), "lm_slab_emit")
-            if stride and self.world > 1:
+            if stride and self.dist is not None:
                 self._all_gather(gathered, mine)
             status = e.L.check(lib.lm_slab_step(e.h, gathered.data_ptr(), stride, (C.c_int64 * self.world)(*lens)), "lm_slab_step")
             if status == 1:
@@ -109,7 +109,7 @@ class ShardedPipeline:
         oh, ow = self.res
         bbox = self._tensor("bbox", (maxc, 4), torch.int32)
         lab_all = self._tensor("lab_all", (self.world * maxc, oh, ow), torch.uint8)
-        lab_loc = lab_all[self.rank * maxc : (self.rank + 1) * maxc] if self.world > 1 else lab_all
+        lab_loc = lab_all[self.rank * maxc : (self.rank + 1) * maxc]
         return bounds, bbox, lab_all, lab_loc
 
     def apply_shard(self, vol_shard: torch.Tensor, n_total: int) -> torch.Tensor:
@@ -138,7 +138,8 @@ class ShardedPipeline:
         counts = [bounds[r + 1] - bounds[r] for r in range(self.world)]
         n_r, maxc = counts[self.rank], max(counts)
         oh, ow = self.res
-        slabs = self.sharded_post and self.world > 1 and min(counts) >= 1 and n_total > 1
+        # (a process group of ONE rank still runs the exchange protocol: that is how the RCCL calls are exercised on a 1-GPU box)
+        slabs = self.sharded_post and self.dist is not None and min(counts) >= 1 and n_total > 1
         if slabs:
             # ---- post-processing on the own slab; six small exchanges inside (no label all-gather at all)
             mine_lab = lab_loc[:n_r]
@@ -146,7 +147,7 @@ class ShardedPipeline:
                 self.postprocess_slab(mine_lab, bounds[self.rank], n_total)
         else:
             # ---- exchange #1: 256^2 label shards -> whole label volume on every rank (RCCL all-gather, in place)
-            if self.world > 1:
+            if self.dist is not None:
                 self._all_gather(lab_all.view(-1), lab_loc.reshape(-1))
                 if any(c != maxc for c in counts):  # ragged tail: compact the padded shards
                     full = torch.cat([lab_all[r * maxc : r * maxc + counts[r]] for r in range(self.world)]).contiguous()
@@ -160,12 +161,12 @@ class ShardedPipeline:
             mine_lab = full[bounds[self.rank] : bounds[self.rank + 1]]
         # ---- un-crop own slices
         out_all = self._tensor("out_all", (self.world * maxc, h, w), torch.uint8)
-        out_loc = out_all[self.rank * maxc : (self.rank + 1) * maxc] if self.world > 1 else out_all
+        out_loc = out_all[self.rank * maxc : (self.rank + 1) * maxc]
         if n_r:
             e.L.check(lib.lm_reshape_mask_dev(e.h, mine_lab.data_ptr(), bbox.data_ptr(), n_r, oh, ow, h, w, out_loc.data_ptr()), "lm_reshape_mask_dev")
         e.sync()
         # ---- exchange #2: output shards
-        if self.world > 1:
+        if self.dist is not None:
             self._all_gather(out_all.view(-1), out_loc.reshape(-1))
             if any(c != maxc for c in counts):
                 return torch.cat([out_all[r * maxc : r * maxc + counts[r]] for r in range(self.world)]).contiguous()

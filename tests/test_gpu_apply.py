@@ -133,6 +133,35 @@ def test_sharded_pipeline_world1_on_torch_cuda_tensors(gpu_engine):
     assert np.array_equal(out, gpu_engine.apply(0, vol, batch_size=20))
 
 
+def test_sharded_pipeline_over_rccl_process_group_of_one(gpu_engine):
+    """The N>1 code path with its real transport: an RCCL ("nccl") process group -- of one rank, all a 1-GPU box allows --
+    so every all_gather_into_tensor of the pipeline (int64 lengths, int32 tables/faces, uint8 volumes, in-place views) and the
+    slab-sharded post-processing protocol run on the device exactly as they do with 8 ranks."""
+    import socket
+
+    import torch.distributed as dist
+
+    from lungmask_amd.pipeline import ShardedPipeline
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        sd = uo.synthetic_state_dict(3)
+        gpu_engine.load_state_dict(0, sd)
+        vol = po.phantom(25, 512, 512, seed=12)
+        expect = gpu_engine.apply(0, vol, batch_size=20)
+        vt = torch.from_numpy(vol).to("cuda:0")
+        for sharded_post in (True, False):
+            pipe = ShardedPipeline(gpu_engine, slot=0, batch_size=20, dist=dist, device="cuda:0", sharded_post=sharded_post)
+            out = pipe.apply_shard(vt, len(vol)).cpu().numpy()
+            assert np.array_equal(out, expect), sharded_post
+    finally:
+        dist.destroy_process_group()
+
+
 def test_apply_is_independent_of_batch_size_and_lanes(gpu_engine):
     sd = uo.synthetic_state_dict(3)
     gpu_engine.load_state_dict(0, sd)
