@@ -171,3 +171,22 @@ def check_slab_postprocess(engines, shapes=((9, 24, 20), (5, 16, 16)), seeds=ran
         assert np.array_equal(out, g[f"post{i}_out"]), (i, lab.shape, spare)
         n_checked += 1
     return n_checked
+
+
+def check_postprocess_noise(eng):
+    """(1) dense label noise (a few percolating regions); (2) a lattice in which EVERY voxel is a region of its own with
+    four foreign face neighbours: one distinct boundary record per voxel, so the per-workgroup record table of
+    boundary_records_kernel (512 slots per 2048 voxels) overflows and most records take the bypass path."""
+    rng = np.random.default_rng(3)
+    lab = rng.integers(0, 4, size=(6, 48, 48)).astype(np.uint8)
+    assert np.array_equal(eng.postprocess(lab), po.postprocessing(lab.copy()))
+    lat = np.zeros((5, 32, 32), np.uint8)
+    yy, xx = np.mgrid[0:32, 0:32]
+    for z in (0, 2, 4):
+        lat[z] = 1 + (xx % 2) + 2 * (yy % 2)
+    lat[2, 8:12, 8:12] = 1  # one larger region for the small ones to merge into
+    for skip in (1, 3):
+        out = eng.postprocess(lat, skip_below=skip)
+        info = eng.postprocess_info()
+        assert info["regions"] > 3000 and info["boundary_records"] > 512 * ((lat.size + 2047) // 2048), info
+        assert np.array_equal(out, po.postprocessing(lat.copy(), skip_below=skip)), skip

@@ -251,3 +251,38 @@ def test_oriented_volumes_and_image_file_formats(gpu_engine, tmp_path):
     op = str(tmp_path / "from_dicom.npy")
     assert main([str(dd), op, "--modelpath", str(wp), "--noprogress"]) == 0
     assert np.array_equal(np.load(op), expect)
+
+
+def test_two_engine_handles_from_two_threads(gpu_engine):
+    """a handle is not thread-safe, DISTINCT handles are -- the serving recipe (one handle per in-flight
+    volume; `tools/serving_throughput.py`): two threads, two handles, interleaved volumes, results identical to a serial run."""
+    import threading
+
+    from lungmask_amd import _native as nat
+
+    sd = uo.synthetic_state_dict(3)
+    gpu_engine.load_state_dict(0, sd)
+    vols = [po.phantom(24, 512, 512, seed=70 + i) for i in range(2)]
+    expect = [gpu_engine.apply(0, v) for v in vols]
+    engines = [nat.Engine(0) for _ in range(2)]
+    got = [[None, None], [None, None]]
+    errs = []
+
+    def work(i):
+        try:
+            engines[i].load_state_dict(0, sd)
+            for rep in range(3):
+                for k in range(2):
+                    got[i][k] = engines[i].apply(0, vols[(k + i) % 2])
+        except Exception as ex:  # surfaced below
+            errs.append(ex)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for e in engines:
+        e.close()
+    assert not errs, errs
+    for i in range(2):
+        for k in range(2):
+            assert np.array_equal(got[i][k], expect[(k + i) % 2]), (i, k)

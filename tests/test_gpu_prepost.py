@@ -32,10 +32,7 @@ def test_postprocessing_random_differential(gpu_engine):
 
 
 def test_postprocessing_noise_volume(gpu_engine):
-    rng = np.random.default_rng(3)
-    lab = rng.integers(0, 4, size=(6, 48, 48)).astype(np.uint8)
-    out = gpu_engine.postprocess(lab)
-    assert np.array_equal(out, po.postprocessing(lab.copy()))
+    cases.check_postprocess_noise(gpu_engine)
 
 
 def test_fusion(gpu_engine):
