@@ -99,8 +99,8 @@ def main():
     import torch
 
     from lungmask_amd import _native as nat
-    from oracle import prepost_oracle as po
-    from oracle import unet_oracle as uo
+    from lungmask_amd import synthetic as po  # phantom + seeded stand-in weights (no oracle code in the timed job)
+    uo = po
 
     dist = None
     # LM_BENCH_FORCE_DIST=1: take the multi-GPU code path (RCCL process group, ShardedPipeline) with a world of one,
@@ -115,7 +115,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     eng = nat.Engine(local_rank)  # raises if liblungmask_hip.so or the GPU is missing: no fallback
-    weights = "synthetic (oracle.unet_oracle.synthetic_state_dict, seed 231)"
+    weights = "synthetic (lungmask_amd.synthetic.synthetic_state_dict, seed 231)"
     sd = None
     wd = os.environ.get("LUNGMASK_WEIGHTS_DIR")
     if wd and os.path.exists(os.path.join(wd, "unet_r231-d5d2fc3d.pth")):

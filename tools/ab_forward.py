@@ -3,7 +3,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from lungmask_amd import _native as nat
-from oracle import unet_oracle as uo
+from lungmask_amd import synthetic as uo
 sd = uo.synthetic_state_dict(3)
 x_h = np.random.default_rng(0).random((300, 256, 256), dtype=np.float32)
 outs = []

@@ -1,7 +1,7 @@
 import sys; sys.path.insert(0,'/root/repo')
 import numpy as np
 from lungmask_amd import _native as nat
-from oracle import unet_oracle as uo
+from lungmask_amd import synthetic as uo
 eng = nat.Engine(0)
 eng.load_state_dict(0, uo.synthetic_state_dict(3))
 g = np.load('/root/repo/tests/golden/unet_c3.npz')

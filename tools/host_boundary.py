@@ -2,7 +2,7 @@
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")
-from oracle import prepost_oracle as po, unet_oracle as uo
+from lungmask_amd import synthetic as uo; po = uo
 from lungmask_amd import _native
 
 eng = _native.Engine(0)

@@ -3,7 +3,7 @@ argv[1]: none | init (init_process_group only) | coll (init + one collective) ; 
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
-from oracle import unet_oracle as uo
+from lungmask_amd import synthetic as uo
 from lungmask_amd import _native as nat
 import torch.distributed as dist
 mode, order = sys.argv[1], sys.argv[2]

@@ -3,7 +3,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from lungmask_amd import _native as nat
-from oracle import unet_oracle as uo
+from lungmask_amd import synthetic as uo
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5

@@ -3,7 +3,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from lungmask_amd import _native as nat
-from oracle import unet_oracle as uo
+from lungmask_amd import synthetic as uo
 B = 20; iters = 12
 sd = uo.synthetic_state_dict(3)
 engs = [nat.Engine(0) for _ in range(3)]

@@ -3,7 +3,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from lungmask_amd import _native as nat
-from oracle import unet_oracle as uo
+from lungmask_amd import synthetic as uo
 eng = nat.Engine(0); eng.load_state_dict(0, uo.synthetic_state_dict(3))
 n = 300
 x = eng.to_device(np.random.default_rng(0).random((n, 256, 256), dtype=np.float32)); lab = eng.empty((n, 256, 256), np.uint8)

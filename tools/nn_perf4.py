@@ -4,7 +4,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from lungmask_amd import _native as nat
-from oracle import unet_oracle as uo
+from lungmask_amd import synthetic as uo
 eng = nat.Engine(0); eng.load_state_dict(0, uo.synthetic_state_dict(3))
 lib = eng.L.lib
 for n in (300, 320):

@@ -2,7 +2,7 @@
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
-from oracle import prepost_oracle as po, unet_oracle as uo
+from lungmask_amd import synthetic as uo; po = uo
 from lungmask_amd import _native as nat
 from lungmask_amd.pipeline import ShardedPipeline
 import torch.distributed as dist

@@ -4,7 +4,7 @@ releases the GIL); while one handle post-processes / copies, the other's network
 import sys, time, threading
 import numpy as np
 sys.path.insert(0, ".")
-from oracle import prepost_oracle as po, unet_oracle as uo
+from lungmask_amd import synthetic as uo; po = uo
 from lungmask_amd import _native as nat
 
 sd = uo.synthetic_state_dict(3)

@@ -3,7 +3,7 @@ after the other; the exchanges are device copies here).  Per-step wall time of r
 import sys, time, ctypes as C
 import numpy as np
 sys.path.insert(0, ".")
-from oracle import prepost_oracle as po, unet_oracle as uo
+from lungmask_amd import synthetic as uo; po = uo
 from lungmask_amd import _native as nat
 from lungmask_amd.pipeline import shard_bounds
 
