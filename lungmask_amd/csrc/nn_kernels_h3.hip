@@ -257,7 +257,7 @@ __device__ __forceinline__ float4 as_float4(const lm_h16x8& v) {
     } while (0)
 
 template <int TAPS, bool G16>
-__global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptiles, int n_items) {
+__global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptiles, int n_items, int xcd_order) {
     using SM = H3WSmem<TAPS, G16>;
     constexpr int HALO = SM::HALO, PW = SM::PW, TWW = SM::TWW, NW = SM::NW, ROWB = PW * 64, NTSTEP = SM::NTSTEP;
     constexpr int PSTR = 272;                   // staged pixel stride of the epilogue: 256 B of split data + 16 B pad
@@ -314,9 +314,25 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
     const int nchunks = p.Cin / KC;
     const bool bn = p.bn_s != nullptr;
 
-    auto decode = [&](int it, int& b, int& y0, int& x0, int& n0) {
-        const int ct = it / n_ptiles;
-        int pt = it - ct * n_ptiles;
+    // Work-item order.  `it` runs over a (padded) index space; workgroup g takes it = g, g + grid, ... and lives on XCD
+    // g % 8 (workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MB L2).
+    //   xcd_order = 0: cout tile major -- every concurrent workgroup streams a DIFFERENT activation tile, and each tile
+    //     is fetched from HBM once per cout tile (Cout/64 times).
+    //   xcd_order = 1: it -> XCD x = it % 8, then cout tile fastest, then pixel tile (pt = 8 * ptl + x): the 32
+    //     workgroups that run together on one XCD work on a few pixel tiles x ALL cout tiles, so an activation tile is
+    //     fetched once and hit in that XCD's L2 by the other cout tiles.  Returns false for the padding of the last row.
+    const int n_ct = p.Cout / TN;
+    auto decode = [&](int it, int& b, int& y0, int& x0, int& n0) -> bool {
+        int ct, pt;
+        if (xcd_order) {
+            const int x = it & 7, s = it >> 3;
+            ct = s % n_ct;
+            pt = (s / n_ct) * 8 + x;
+        } else {
+            ct = it / n_ptiles;
+            pt = it - ct * n_ptiles;
+        }
+        const bool valid = pt < n_ptiles;
         const int tx = pt % tiles_x;
         pt /= tiles_x;
         const int tiles_y = (p.H + TH - 1) / TH;
@@ -325,6 +341,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
         y0 = ty * TH;
         x0 = tx * TWW;
         n0 = ct * TN;
+        return valid;
     };
 
     // Stage chunk c0 of item (b,y0,x0,n0) into buffer `par`.  Compiler-visible LDS stores (zero fill of the
@@ -363,13 +380,13 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
 
     lm_f32x16 accm[2][2], accc[2][2];  // [M-tile][N-tile = row]
     int it = blockIdx.x;
+    int b, y0, x0, n0;
+    while (it < n_items && !decode(it, b, y0, x0, n0)) it += gridDim.x;
     if (it >= n_items) return;
     if (!bn && tid < 2 * TN) {  // no BatchNorm (decoder 1x1): identity constants, never overwritten
         epi[0][1 + tid / TN][tid % TN] = tid < TN ? 1.f : 0.f;
         epi[1][1 + tid / TN][tid % TN] = tid < TN ? 1.f : 0.f;
     }
-    int b, y0, x0, n0;
-    decode(it, b, y0, x0, n0);
     int par = 0, epar = 0;
     issue(b, y0, x0, n0, 0, par, true, epar);
     while (true) {
@@ -382,10 +399,10 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                     accm[i][j][r] = 0.f;
                     accc[i][j][r] = 0.f;
                 }
-        const int nit = it + gridDim.x;
-        const bool have_next = nit < n_items;
+        int nit = it + gridDim.x;
         int nb = 0, ny0 = 0, nx0 = 0, nn0 = 0;
-        if (have_next) decode(nit, nb, ny0, nx0, nn0);
+        while (nit < n_items && !decode(nit, nb, ny0, nx0, nn0)) nit += gridDim.x;
+        const bool have_next = nit < n_items;
         for (int ci = 0; ci < nchunks; ++ci) {
             lm_dma_wait_all();
             __syncthreads();  // chunk ci of this item has landed in buffer `par`; everyone is done with the other buffer
@@ -505,7 +522,11 @@ static hipError_t launch_conv_h3_t(const ConvParamsH3& p, hipStream_t stream) {
     const bool g16 = p.W == 16;
     if (wide_ok && (p.W % 32 == 0 || g16) && (size_t)2 * p.H * p.W * p.in_cstride * 4 < 0x7fffffffull && (size_t)TAPS * p.Cout * p.Cin * 4 < 0x7fffffffull) {
         const int n_ptiles = g16 ? ((p.H + TH - 1) / TH) * ((p.B + 1) / 2) : (p.W / 32) * ((p.H + TH - 1) / TH) * p.B;
-        const int n_items = n_ptiles * (p.Cout / TN);
+        // LM_H3_ORDER: 0 cout-major everywhere, 1 XCD-aware pixel-tile-major everywhere, default: per layer (see below)
+        static const int order_env = [] { const char* e = getenv("LM_H3_ORDER"); return e ? atoi(e) : -1; }();
+        const int n_ct = p.Cout / TN;
+        const int xcd_order = order_env >= 0 ? order_env : (n_ct >= 2 && n_ptiles >= 64 ? 1 : 0);
+        const int n_items = xcd_order ? 8 * ((n_ptiles + 7) / 8) * n_ct : n_ptiles * n_ct;
         static const int n_cu = [] {
 #ifdef LM_EMU_BUILD
             return 4;
@@ -517,9 +538,9 @@ static hipError_t launch_conv_h3_t(const ConvParamsH3& p, hipStream_t stream) {
         }();
         const unsigned blocks = (unsigned)std::min(n_items, n_cu);
         if (g16)
-            LM_LAUNCH((conv_igemm_h3p<TAPS, true>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items);
+            LM_LAUNCH((conv_igemm_h3p<TAPS, true>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
         else
-            LM_LAUNCH((conv_igemm_h3p<TAPS, false>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items);
+            LM_LAUNCH((conv_igemm_h3p<TAPS, false>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
         return hipGetLastError();
     }
     const int tiles = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH);

@@ -129,3 +129,38 @@ def test_forward_fallback_kernel_at_full_size():
     env = dict(os.environ, LM_H3_FALLBACK="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("order", ["0", "1"])
+def test_forward_work_item_orders_agree(order):
+    """The persistent conv kernel picks its work-item order per layer (cout-major, or XCD-aware pixel-tile-major over a
+    padded index space).  LM_H3_ORDER forces one order everywhere: both must give the oracle's result -- also with an
+    odd batch, where the padded space has holes."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "from lungmask_amd import _native as nat\n"
+        "from oracle import unet_oracle as uo\n"
+        "e = nat.Engine(0); sd = uo.synthetic_state_dict(3); e.load_state_dict(0, sd)\n"
+        "x = np.random.default_rng(4).random((3, 256, 256), dtype=np.float32)\n"
+        "lab, logp = e.forward(0, x)\n"
+        "ref = uo.forward(sd, torch.from_numpy(x[:, None])).numpy()\n"
+        "err = float(np.abs(logp - ref).max()); print('ERR', err); assert err < 1e-3\n"
+        "np.save(sys.argv[1], lab)\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "lab.npy")
+        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, LM_H3_ORDER=order), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        lab = np.load(out)
+    from lungmask_amd import _native as nat
+
+    e = nat.Engine(0)  # default (per-layer) order in this process
+    e.load_state_dict(0, uo.synthetic_state_dict(3))
+    mine = e.forward(0, np.random.default_rng(4).random((3, 256, 256), dtype=np.float32), want_logp=False)[0]
+    e.close()
+    assert np.array_equal(lab, mine)  # the order changes nothing but the schedule: bit-identical labels

@@ -1,10 +1,12 @@
-set -x
-python -m pytest tests -m gpu -x -q 2>&1 | tail -5
-LM_BENCH_FORCE_DIST=1 python bench.py --steps 3 --no-cpu-baseline 2>gpurun_out/bench_dist_err.log | tail -1 > gpurun_out/bench_forced_dist.json; cat gpurun_out/bench_forced_dist.json | cut -c1-400
-LM_BENCH_FORCE_DIST=1 python bench.py --steps 3 --no-cpu-baseline --post gathered 2>>gpurun_out/bench_dist_err.log | tail -1 > gpurun_out/bench_forced_dist_gathered.json; cat gpurun_out/bench_forced_dist_gathered.json | cut -c1-300
-python bench.py 2>gpurun_out/bench_err.log | tail -1 > gpurun_out/bench_r01e.json; cat gpurun_out/bench_r01e.json | cut -c1-600
+# Round-end GPU check: full parity suite, smoke, the multi-GPU code path with a world of one, the bench line and the
+# rocprofv3 evidence (kernel stats with one forward lane + separate PMC passes).  Usage: gpurun -- 'bash tools/gpu_round_check.sh r01f'
+TAG=${1:-rXX}
+python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu_$TAG.log 2>&1; grep -E "passed|failed|error" gpurun_out/pytest_gpu_$TAG.log | tail -3
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -2
+LM_BENCH_FORCE_DIST=1 python bench.py --steps 3 --no-cpu-baseline 2>gpurun_out/bench_dist_err.log > gpurun_out/bench_forced_dist_$TAG.txt; tail -1 gpurun_out/bench_forced_dist_$TAG.txt | cut -c1-200
+python bench.py 2>gpurun_out/bench_err.log | tail -1 > gpurun_out/bench_$TAG.json; cut -c1-200 gpurun_out/bench_$TAG.json
 R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r01e/trace -- python $R/bench.py --streams 1 --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_r01e_bench.json 2>$R/gpurun_out/prof_r01e.log
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_r01e/pmc_fetch -- python $R/bench.py --streams 1 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>>$R/gpurun_out/prof_r01e.log
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_r01e/pmc_write -- python $R/bench.py --streams 1 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>>$R/gpurun_out/prof_r01e.log
-ls $R/gpurun_out/prof_r01e/*
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG/trace -- python $R/bench.py --streams 1 --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_${TAG}_bench.json 2>$R/gpurun_out/prof_$TAG.log
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_$TAG/pmc_fetch -- python $R/bench.py --streams 1 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>>$R/gpurun_out/prof_$TAG.log
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_$TAG/pmc_write -- python $R/bench.py --streams 1 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>>$R/gpurun_out/prof_$TAG.log
+ls $R/gpurun_out/prof_$TAG
