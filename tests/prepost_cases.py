@@ -190,3 +190,13 @@ def check_postprocess_noise(eng):
         info = eng.postprocess_info()
         assert info["regions"] > 3000 and info["boundary_records"] > 512 * ((lat.size + 2047) // 2048), info
         assert np.array_equal(out, po.postprocessing(lat.copy(), skip_below=skip)), skip
+
+
+def check_empty_inputs(eng):
+    """Zero-slice volumes through every stage (the reference's loops simply do not iterate): empty outputs, no error."""
+    assert eng.postprocess(np.zeros((0, 8, 8), np.uint8)).shape == (0, 8, 8)
+    xi, xf, bb, _ = eng.preprocess(np.zeros((0, 64, 64), np.int16), resolution=(32, 32))
+    assert xi.shape == (0, 32, 32) and xf.shape == (0, 32, 32) and bb.shape == (0, 4)
+    assert eng.reshape_mask(np.zeros((0, 32, 32), np.uint8), np.zeros((0, 4), np.int32), (64, 64)).shape == (0, 64, 64)
+    fused, spare = eng.fuse(np.zeros((0, 8, 8), np.uint8), np.zeros((0, 8, 8), np.uint8))
+    assert fused.shape == (0, 8, 8) and spare == 1

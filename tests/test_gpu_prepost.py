@@ -35,6 +35,14 @@ def test_postprocessing_noise_volume(gpu_engine):
     cases.check_postprocess_noise(gpu_engine)
 
 
+def test_empty_inputs(gpu_engine):
+    cases.check_empty_inputs(gpu_engine)
+    from oracle import unet_oracle as uo
+
+    gpu_engine.load_state_dict(0, uo.synthetic_state_dict(3))
+    assert gpu_engine.apply(0, np.zeros((0, 512, 512), np.int16)).shape == (0, 512, 512)
+
+
 def test_fusion(gpu_engine):
     cases.check_fuse(gpu_engine)
 

@@ -27,6 +27,10 @@ def test_postprocessing_emulated_noise_volume(emu_engine):
     cases.check_postprocess_noise(emu_engine)
 
 
+def test_empty_inputs_emulated(emu_engine):
+    cases.check_empty_inputs(emu_engine)
+
+
 def test_fusion_emulated(emu_engine):
     cases.check_fuse(emu_engine)
 
