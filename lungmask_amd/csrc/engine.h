@@ -41,7 +41,8 @@ struct DevBuf {
 
 struct ConvLayer {
     float *w = nullptr, *bias = nullptr, *bn_s = nullptr, *bn_t = nullptr;
-    char* w_h3 = nullptr;  // split-f16 packing [taps][Cout][Cin/8][hi8|lo8]
+    char* w_h3 = nullptr;  // split-f16 packing [taps][Cout][Cin/8][hi8|lo8] of w * 2^k
+    float h3_acc_scale = 1.f;  // 2^-k
     int cin = 0, cout = 0, taps = 0;
 };
 

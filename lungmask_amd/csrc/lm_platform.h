@@ -95,13 +95,14 @@ __device__ __forceinline__ void lm_global_load_lds4(const void* gsrc, void* lds_
 #endif
 }
 
-// fp32 x4 -> split-f16: hi = f16(v), lo = f16((v - hi) * 2048), each packed as 4 halves (8 bytes).
-// The vector form makes hipcc emit v_cvt_pk_f16_f32 / v_pk_add_f32 / v_pk_mul_f32 (3 VALU per value).
+// fp32 x4 -> split-f16: hi = f16(v), lo = f16(v - hi) (UNSCALED: for |v| < 2^-3 the remainder is an f16 denormal, which
+// conversions and the matrix instructions honour -- tools/ubench/mfma_denorm.hip -- so v = hi + lo to 2^-25 absolute or
+// 2^-22 relative, whichever is larger), each packed as 4 halves (8 bytes).
+// The vector form makes hipcc emit v_cvt_pk_f16_f32 / v_pk_add_f32 (2 VALU per value).
 __device__ __forceinline__ void lm_split4(float v0, float v1, float v2, float v3, uint2* hi, uint2* lo) {
 #ifdef LM_EMU_BUILD
     lm_h16 h[4] = {lm_f2h(v0), lm_f2h(v1), lm_f2h(v2), lm_f2h(v3)};
-    lm_h16 l[4] = {lm_f2h((v0 - lm_h2f(h[0])) * 2048.0f), lm_f2h((v1 - lm_h2f(h[1])) * 2048.0f),
-                   lm_f2h((v2 - lm_h2f(h[2])) * 2048.0f), lm_f2h((v3 - lm_h2f(h[3])) * 2048.0f)};
+    lm_h16 l[4] = {lm_f2h(v0 - lm_h2f(h[0])), lm_f2h(v1 - lm_h2f(h[1])), lm_f2h(v2 - lm_h2f(h[2])), lm_f2h(v3 - lm_h2f(h[3]))};
     memcpy(hi, h, 8);
     memcpy(lo, l, 8);
 #else
@@ -109,7 +110,7 @@ __device__ __forceinline__ void lm_split4(float v0, float v1, float v2, float v3
     typedef float f4 __attribute__((ext_vector_type(4)));
     const f4 v = {v0, v1, v2, v3};
     const h4 h = __builtin_convertvector(v, h4);
-    const f4 r = (v - __builtin_convertvector(h, f4)) * 2048.0f;
+    const f4 r = v - __builtin_convertvector(h, f4);
     const h4 l = __builtin_convertvector(r, h4);
     __builtin_memcpy(hi, &h, 8);
     __builtin_memcpy(lo, &l, 8);

@@ -194,15 +194,27 @@ int load_conv(Model& md, const TensorMap& tm, const std::string& conv, const std
             for (int t = 0; t < taps; ++t) pw[((size_t)t * cin + i) * cout + o] = w->data[((size_t)o * cin + i) * taps + t];
     LM_TRY(upload(md, pw, &L->w));
     LM_TRY(upload(md, std::vector<float>(b->data, b->data + cout), &L->bias));
-    if (cin % 8 == 0) {  // split-f16 packing: [tap][cout][cin/8 groups][8 hi | 8 lo], lo = f16((w - hi) * 2048)
+    if (cin % 8 == 0) {  // split-f16 packing: [tap][cout][cin/8 groups][8 hi | 8 lo] of w' = w * 2^k, lo = f16(w' - hi)
+        // k: the layer's largest |w'| lands in [8, 16), so the remainders of all but the tiniest weights are NORMAL f16
+        // numbers (full 11-bit precision of lo -> 2^-22 relative on w); 2^-k goes back in through the epilogue.
+        float wmax = 0.f;
+        for (size_t j = 0; j < (size_t)taps * cout * cin; ++j) wmax = std::max(wmax, std::fabs(w->data[j]));
+        int k = 0;
+        if (wmax > 0.f && std::isfinite(wmax)) {
+            int e = 0;
+            (void)std::frexp(wmax, &e);  // wmax = m * 2^e, m in [0.5, 1)
+            k = 4 - e;                   // wmax * 2^k in [8, 16)
+        }
+        const float up = std::ldexp(1.f, k);
+        L->h3_acc_scale = std::ldexp(1.f, -k);
         std::vector<float> ph((size_t)taps * cout * cin);  // 4 bytes per element, viewed as halves below
         uint16_t* hp = reinterpret_cast<uint16_t*>(ph.data());
         for (int t = 0; t < taps; ++t)
             for (int o = 0; o < cout; ++o)
                 for (int i = 0; i < cin; ++i) {
-                    const float v = w->data[((size_t)o * cin + i) * taps + t];
+                    const float v = w->data[((size_t)o * cin + i) * taps + t] * up;
                     const uint16_t hi = f32_to_f16(v);
-                    const uint16_t lo = f32_to_f16((v - f16_to_f32(hi)) * 2048.0f);
+                    const uint16_t lo = f32_to_f16(v - f16_to_f32(hi));
                     const size_t g = (((size_t)t * cout + o) * cin + (size_t)(i & ~7)) * 2;  // half index of the group start
                     hp[g + (i & 7)] = hi;
                     hp[g + 8 + (i & 7)] = lo;
@@ -329,6 +341,7 @@ struct Fwd {
             q.in_cstride = in_cs;
             q.in_coff = in_co;
             q.w = L.w_h3;
+            q.acc_scale = L.h3_acc_scale;
             q.bias = L.bias;
             q.bn_s = L.bn_s;
             q.bn_t = L.bn_t;

@@ -52,11 +52,12 @@ struct HeadParams {
 };
 
 // Split-f16 variant (nn_kernels_h3.hip): tensors are "split NHWC" byte buffers (4 bytes per element:
-// groups of 8 channels = 8 hi halves + 8 lo halves); strides/offsets are still counted in channels.
+// groups of 8 channels = 8 hi halves + 8 lo halves, v = hi + lo); strides/offsets are still counted in channels.
 struct ConvParamsH3 {
     const char* in;
     int in_cstride, in_coff;
-    const char* w;  // packed [taps][Cout][Cin/8 groups][hi8|lo8]
+    const char* w;  // packed [taps][Cout][Cin/8 groups][hi8|lo8] of w * 2^k (k per layer, so that lo stays a normal f16)
+    float acc_scale;  // 2^-k: applied to the accumulator in the epilogue
     const float* bias;
     const float* bn_s;
     const float* bn_t;

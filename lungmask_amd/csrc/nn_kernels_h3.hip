@@ -1,12 +1,13 @@
 // Split-f16 ("3-product") U-Net kernels: fp32-class accuracy on the 16-bit matrix cores.
 //
 // Every fp32 value v is carried as a pair of halves
-//      hi = f16(v),   lo = f16((v - hi) * 2048)          =>  v = hi + lo/2048  to ~2^-22 relative
-// (the 2^11 scale keeps `lo` in the normal f16 range).  A product a*w is evaluated as
-//      a_hi*w_hi  +  (a_hi*w_lo + a_lo*w_hi) / 2048       (the lo*lo term, 2^-22 relative, is dropped)
-// with two fp32 MFMA accumulators (main, correction) of v_mfma_f32_32x32x16_f16: three matrix
-// instructions per 16-deep k-block, i.e. an effective peak of 2.5 PFLOP/s / 3 = 833 TFLOP/s against
-// 157 TFLOP/s for the exact-fp32 matrix op.
+//      hi = f16(v),   lo = f16(v - hi)                   =>  v = hi + lo  to ~2^-22 relative
+// (lo is stored UNSCALED: for activations of O(1) it is a normal f16 number, for tiny ones an f16 denormal with 2^-25
+// absolute error -- conversions and the matrix instructions honour denormals; weights are pre-multiplied by a power
+// of two per layer so that their remainders are normal too, and 2^-k comes back in the epilogue).  A product a*w is
+//      a_hi*w_hi  +  a_hi*w_lo + a_lo*w_hi                 (the lo*lo term, 2^-22 relative, is dropped)
+// -- three v_mfma_f32_32x32x16_f16 per 16-deep k-block into ONE fp32 accumulator, i.e. an effective peak of
+// 2.5 PFLOP/s / 3 = 833 TFLOP/s against 157 TFLOP/s for the exact-fp32 matrix op.
 //
 // Storage ("split NHWC"): channels in groups of 8; a group is 32 bytes = 8 hi halves then 8 lo halves.
 // A pixel with C channels is C/8 groups = 4*C bytes -- the same footprint and strides as fp32 NHWC,
@@ -30,7 +31,6 @@ namespace lm {
 namespace {
 
 constexpr int TH = 16, TW = 16, TN = 64, KC = 16;
-constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
 
 // Staging through LDS reads back, as 16-byte units, bytes that were written as 8-byte units: these accesses
 // must be exempt from type-based alias analysis or the loads may be hoisted above the stores.
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(ConvParamsH3 p) {
     const int b = t / tiles_y;
     const int x0 = tx * TW, y0 = ty * TH, n0 = blockIdx.y * TN;
 
-    lm_f32x16 accm[2][2], accc[2][2];
+    lm_f32x16 accm[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -84,7 +84,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(ConvParamsH3 p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 accm[i][j][r] = 0.f;
-                accc[i][j][r] = 0.f;
             }
 
     const int li = lane & 31, kb = lane >> 5;
@@ -140,8 +139,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(ConvParamsH3 p) {
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     accm[mt][nt] = lm_mfma_f32_32x32x16_f16(whi[mt], ahi[nt], accm[mt][nt]);
-                    accc[mt][nt] = lm_mfma_f32_32x32x16_f16(whi[mt], alo[nt], accc[mt][nt]);
-                    accc[mt][nt] = lm_mfma_f32_32x32x16_f16(wlo[mt], ahi[nt], accc[mt][nt]);
+                    accm[mt][nt] = lm_mfma_f32_32x32x16_f16(whi[mt], alo[nt], accm[mt][nt]);
+                    accm[mt][nt] = lm_mfma_f32_32x32x16_f16(wlo[mt], ahi[nt], accm[mt][nt]);
                 }
         }
     }
@@ -163,10 +162,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(ConvParamsH3 p) {
                 const int cb = n0 + 32 * mt + 8 * g + 4 * kb;  // first of 4 consecutive output channels
                 const float4 bias = *reinterpret_cast<const float4*>(p.bias + cb);
                 float v[4];
-                v[0] = fmaf(accc[mt][nt][4 * g + 0], kLoInv, accm[mt][nt][4 * g + 0]) + bias.x;
-                v[1] = fmaf(accc[mt][nt][4 * g + 1], kLoInv, accm[mt][nt][4 * g + 1]) + bias.y;
-                v[2] = fmaf(accc[mt][nt][4 * g + 2], kLoInv, accm[mt][nt][4 * g + 2]) + bias.z;
-                v[3] = fmaf(accc[mt][nt][4 * g + 3], kLoInv, accm[mt][nt][4 * g + 3]) + bias.w;
+                v[0] = fmaf(accm[mt][nt][4 * g + 0], p.acc_scale, bias.x);
+                v[1] = fmaf(accm[mt][nt][4 * g + 1], p.acc_scale, bias.y);
+                v[2] = fmaf(accm[mt][nt][4 * g + 2], p.acc_scale, bias.z);
+                v[3] = fmaf(accm[mt][nt][4 * g + 3], p.acc_scale, bias.w);
                 if (bn) {
                     const float4 s = *reinterpret_cast<const float4*>(p.bn_s + cb);
                     const float4 sh = *reinterpret_cast<const float4*>(p.bn_t + cb);
@@ -243,17 +242,17 @@ __device__ __forceinline__ float4 as_float4(const lm_h16x8& v) {
         LM_LDS_READ128(f[3], as + w_off_lo, (3 * (DY) + (DX)) * (TN * 64) + 2048);            \
         LM_LDS_WAIT8(0, f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);                      \
         accm[0][0] = lm_mfma_f32_32x32x16_f16(f[0], f[4], accm[0][0]);                        \
-        accc[0][0] = lm_mfma_f32_32x32x16_f16(f[0], f[5], accc[0][0]);                        \
         accm[0][1] = lm_mfma_f32_32x32x16_f16(f[0], f[6], accm[0][1]);                        \
-        accc[0][1] = lm_mfma_f32_32x32x16_f16(f[0], f[7], accc[0][1]);                        \
         accm[1][0] = lm_mfma_f32_32x32x16_f16(f[1], f[4], accm[1][0]);                        \
-        accc[1][0] = lm_mfma_f32_32x32x16_f16(f[1], f[5], accc[1][0]);                        \
         accm[1][1] = lm_mfma_f32_32x32x16_f16(f[1], f[6], accm[1][1]);                        \
-        accc[1][1] = lm_mfma_f32_32x32x16_f16(f[1], f[7], accc[1][1]);                        \
-        accc[0][0] = lm_mfma_f32_32x32x16_f16(f[2], f[4], accc[0][0]);                        \
-        accc[0][1] = lm_mfma_f32_32x32x16_f16(f[2], f[6], accc[0][1]);                        \
-        accc[1][0] = lm_mfma_f32_32x32x16_f16(f[3], f[4], accc[1][0]);                        \
-        accc[1][1] = lm_mfma_f32_32x32x16_f16(f[3], f[6], accc[1][1]);                        \
+        accm[0][0] = lm_mfma_f32_32x32x16_f16(f[0], f[5], accm[0][0]);                        \
+        accm[0][1] = lm_mfma_f32_32x32x16_f16(f[0], f[7], accm[0][1]);                        \
+        accm[1][0] = lm_mfma_f32_32x32x16_f16(f[1], f[5], accm[1][0]);                        \
+        accm[1][1] = lm_mfma_f32_32x32x16_f16(f[1], f[7], accm[1][1]);                        \
+        accm[0][0] = lm_mfma_f32_32x32x16_f16(f[2], f[4], accm[0][0]);                        \
+        accm[0][1] = lm_mfma_f32_32x32x16_f16(f[2], f[6], accm[0][1]);                        \
+        accm[1][0] = lm_mfma_f32_32x32x16_f16(f[3], f[4], accm[1][0]);                        \
+        accm[1][1] = lm_mfma_f32_32x32x16_f16(f[3], f[6], accm[1][1]);                        \
     } while (0)
 
 template <int TAPS, bool G16>
@@ -378,7 +377,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
         }
     };
 
-    lm_f32x16 accm[2][2], accc[2][2];  // [M-tile][N-tile = row]
+    lm_f32x16 accm[2][2];  // [M-tile][N-tile = row]: all three products of the split scheme accumulate here
     int it = blockIdx.x;
     int b, y0, x0, n0;
     while (it < n_items && !decode(it, b, y0, x0, n0)) it += gridDim.x;
@@ -397,7 +396,6 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     accm[i][j][r] = 0.f;
-                    accc[i][j][r] = 0.f;
                 }
         int nit = it + gridDim.x;
         int nb = 0, ny0 = 0, nx0 = 0, nn0 = 0;
@@ -451,7 +449,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                     float v[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        float t = fmaf(accc[mt][nt][4 * g + k], kLoInv, accm[mt][nt][4 * g + k]) + bb[k];
+                        float t = fmaf(accm[mt][nt][4 * g + k], p.acc_scale, bb[k]);
                         if (bn) t = fmaf(fmaxf(t, 0.f), ss[k], tt[k]);
                         v[k] = t;
                         if (!G16) pl[mg][k] = nt == 0 ? t : pl[mg][k] + t;
@@ -590,7 +588,7 @@ __global__ __launch_bounds__(256) void first_conv_h3_kernel(FirstConvParams p) {
             char* g = out + ((((size_t)b * p.H + y) * p.W + x) * p.out_cstride + p.out_coff) * 4 + (size_t)(lane >> 3) * 32 + (lane & 7) * 2;
             const lm_h16 h = lm_f2h(v);
             *reinterpret_cast<lm_h16*>(g) = h;
-            *reinterpret_cast<lm_h16*>(g + 16) = lm_f2h((v - lm_h2f(h)) * kLoScale);
+            *reinterpret_cast<lm_h16*>(g + 16) = lm_f2h(v - lm_h2f(h));
         }
     }
 }
@@ -608,7 +606,7 @@ __device__ __forceinline__ void load_group(const char* g, float* v) {  // 32-byt
     memcpy(hh, &a, 16);
     memcpy(ll, &c, 16);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = fmaf(lm_h2f(ll[k]), kLoInv, lm_h2f(hh[k]));
+    for (int k = 0; k < 8; ++k) v[k] = lm_h2f(ll[k]) + lm_h2f(hh[k]);
 }
 }  // namespace
 
