@@ -1,6 +1,6 @@
-"""max |delta log-prob| of the engine vs the torch-fp32 reference forward on random inputs (argv: library paths)."""
+"""(test-side tool: it uses the oracle as the checker)  max |delta log-prob| of the engine vs the torch-fp32 reference forward on random inputs (argv: library paths)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 import numpy as np, torch
 from lungmask_amd import _native as nat
 from oracle import unet_oracle as uo
