@@ -73,7 +73,7 @@ int lm_model_classes(lm_engine* e, int slot);
 
 /* Arithmetic of the convolutions: 1 (default) = split-f16 3-product on v_mfma_f32_32x32x16_f16
  * (values carried as hi/lo f16 pairs, fp32 accumulate; ~2^-22 relative, i.e. fp32-class:
- * measured max |log-prob error| vs the reference <= 1.2e-4); 0 = exact fp32 matrix ops
+ * measured max |log-prob error| vs the reference <= 1.7e-4); 0 = exact fp32 matrix ops
  * (v_mfma_f32_32x32x2_f32, 16x lower peak). */
 int lm_set_precision(lm_engine* e, int mode);
 
