@@ -117,6 +117,27 @@ __device__ __forceinline__ void lm_split4(float v0, float v1, float v2, float v3
 #endif
 }
 
+// the values a consumer of the split pair sees: v' = f32(hi) + f32(lo)
+__device__ __forceinline__ void lm_unsplit4(uint2 hi, uint2 lo, float* out) {
+#ifdef LM_EMU_BUILD
+    lm_h16 h[4], l[4];
+    memcpy(h, &hi, 8);
+    memcpy(l, &lo, 8);
+    for (int k = 0; k < 4; ++k) out[k] = lm_h2f(l[k]) + lm_h2f(h[k]);
+#else
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    h4 h, l;
+    __builtin_memcpy(&h, &hi, 8);
+    __builtin_memcpy(&l, &lo, 8);
+    const f4 r = __builtin_convertvector(l, f4) + __builtin_convertvector(h, f4);
+    out[0] = r[0];
+    out[1] = r[1];
+    out[2] = r[2];
+    out[3] = r[3];
+#endif
+}
+
 // 16-byte LDS reads that the compiler's waitcnt pass cannot see (so it does not drain an in-flight LDS-DMA
 // in front of them), with an explicit counted wait that names every destination register.
 #ifdef LM_EMU_BUILD

@@ -303,8 +303,10 @@ struct Fwd {
     int B;
     int kc3, kc1, kfirst, kup, khead;
 
+    bool head_fused = false;  // set by conv() when the head ran inside the last conv's epilogue
+
     int conv(const ConvLayer& L, const float* in, int in_cs, int in_co, int H, int W, float* out, int out_cs, int out_co,
-             float* pool = nullptr, int pool_cs = 0, int pool_co = 0) {
+             float* pool = nullptr, int pool_cs = 0, int pool_co = 0, const HeadParams* head = nullptr) {
         ConvParams p{};
         p.in = in;
         p.in_cstride = in_cs;
@@ -357,6 +359,13 @@ struct Fwd {
             q.W = W;
             q.Cin = L.cin;
             q.Cout = L.cout;
+            if (head && head->labels && !head->logp && L.taps == 9 && conv3x3_h3_can_fuse_head(q)) {
+                q.head_w = head->w;
+                q.head_b = head->bias;
+                q.head_labels = head->labels;
+                q.head_C = head->C;
+                head_fused = true;
+            }
             err = (L.taps == 9) ? launch_conv3x3_h3(q, st) : launch_conv1x1_h3(q, st);
         } else {
             err = (L.taps == 9) ? launch_conv3x3(p, st) : launch_conv1x1(p, st);
@@ -440,10 +449,12 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
             }
         }
         LM_TRY(f.conv(md.upc[i][0], ws.cat[lvl].as<float>(), 2 * c, 0, h, w, t1, c, 0));
-        LM_TRY(f.conv(md.upc[i][1], t1, c, 0, h, w, t3, c, 0));
+        // the last conv takes the head (1x1 conv + argmax) into its epilogue when only labels are wanted
+        const HeadParams hp{t3, md.head_w, md.head_b, labels, logp, B, H, W, md.n_classes};
+        LM_TRY(f.conv(md.upc[i][1], t1, c, 0, h, w, t3, c, 0, nullptr, 0, 0, i == 3 ? &hp : nullptr));
     }
     // ---- head (resunet.py:69-70, mask.py:184-186)
-    {
+    if (!f.head_fused) {
         HeadParams p{t3, md.head_w, md.head_b, labels, logp, B, H, W, md.n_classes};
         e->prof.begin(stream, f.khead, 2.0 * px * 64 * md.n_classes, 4.0 * px * 64 + px);
         hipError_t err = h3 ? launch_head_h3(p, stream) : launch_head(p, stream);

@@ -67,7 +67,15 @@ struct ConvParamsH3 {
     int pool_cstride, pool_coff;
     const char* zeros;  // >= 16 zero bytes in device memory (source of out-of-image halo pixels)
     int B, H, W, Cin, Cout;
+    // Fused head (last conv of the decoder, Cout == 64): when head_labels is set the conv output is NOT stored; the
+    // 1x1 head conv + argmax (resunet.py:69, mask.py:184-186) run in the epilogue, bit-identical to launch_head_h3.
+    const float* head_w = nullptr;   // [C][64]
+    const float* head_b = nullptr;   // [C]
+    uint8_t* head_labels = nullptr;  // [B][H][W]
+    int head_C = 0;
 };
+// whether launch_conv3x3_h3 can take the fused head for this shape (else run launch_head_h3 on the stored output)
+bool conv3x3_h3_can_fuse_head(const ConvParamsH3& p);
 hipError_t launch_conv3x3_h3(const ConvParamsH3& p, hipStream_t stream);
 hipError_t launch_conv1x1_h3(const ConvParamsH3& p, hipStream_t stream);
 hipError_t launch_first_conv_h3(const FirstConvParams& p, hipStream_t stream);  // out: split tensor

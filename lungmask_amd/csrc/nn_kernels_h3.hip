@@ -265,6 +265,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
     constexpr int STAGE_EXTRA = STAGE_BYTES <= SM::BUF_BYTES ? 0 : STAGE_BYTES;
     __shared__ __attribute__((aligned(1024))) char lds[2 * SM::BUF_BYTES + STAGE_EXTRA];
     __shared__ __attribute__((aligned(16))) float epi[2][3][TN];  // bias, bn scale, bn shift of the item (double buffered)
+    __shared__ __attribute__((aligned(16))) float hw[(TAPS == 9 && !G16) ? kMaxClasses * 64 + kMaxClasses : 4];  // fused head: weights, bias
 
     const int tid = threadIdx.x, lane = tid & 63, wave = lm_uniform(tid >> 6);
     const int li = lane & 31, kb = lane >> 5;
@@ -386,6 +387,11 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
         epi[0][1 + tid / TN][tid % TN] = tid < TN ? 1.f : 0.f;
         epi[1][1 + tid / TN][tid % TN] = tid < TN ? 1.f : 0.f;
     }
+    const bool fuse_head = TAPS == 9 && !G16 && p.head_labels != nullptr;
+    if (TAPS == 9 && !G16 && fuse_head) {
+        for (int i = tid; i < p.head_C * 64; i += 512) hw[i] = p.head_w[i];
+        if (tid < p.head_C) hw[kMaxClasses * 64 + tid] = p.head_b[tid];
+    }
     int par = 0, epar = 0;
     issue(b, y0, x0, n0, 0, par, true, epar);
     while (true) {
@@ -429,6 +435,68 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
             const int yb = y0 + (G16 ? 4 * (wave & 3) : 2 * wave);  // first image row of the wave's N-tile 0
             const int Hp = p.H >> 1, Wp = p.W >> 1;
             const char* ep = reinterpret_cast<const char*>(&epi[epar][0][0]);
+            if (TAPS == 9 && !G16 && fuse_head) {
+                // ---- fused head: this item holds ALL 64 channels of its pixels (n0 == 0).  Per pixel the two lanes kb = 0/1
+                // own channels 8q + 4kb + k (q = mg, k = 0..3).  launch_head_h3 sums each 8-channel block as one fma chain
+                // (k = 0..7 from 0) and then adds the blocks pairwise (q ^ 4, q ^ 2, q ^ 1): the chain is continued across
+                // the lane pair with one shuffle and the pairwise tree is evaluated in registers, on the values a reader of
+                // the split tensor would see (hi + lo) -- the labels are bit-identical to the unfused path.
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int yl = yb + nt;
+                    const bool tile_ok = bs < p.B && yl < p.H;
+                    float vv[8][4];
+#pragma unroll
+                    for (int mg = 0; mg < 8; ++mg) {
+                        const int mt = mg >> 2, g = mg & 3;
+                        const int cl = 32 * mt + 8 * g + 4 * kb;
+                        lm_h16x8 e0, e1, e2;
+                        LM_LDS_READ128(e0, ep + cl * 4, 0);
+                        LM_LDS_READ128(e1, ep + cl * 4, TN * 4);
+                        LM_LDS_READ128(e2, ep + cl * 4, 2 * TN * 4);
+                        LM_LDS_WAIT3(0, e0, e1, e2);
+                        const float4 bias = as_float4(e0), s = as_float4(e1), sh = as_float4(e2);
+                        const float bb[4] = {bias.x, bias.y, bias.z, bias.w}, ss[4] = {s.x, s.y, s.z, s.w}, tt[4] = {sh.x, sh.y, sh.z, sh.w};
+                        float v[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            float t = fmaf(accm[mt][nt][4 * g + k], p.acc_scale, bb[k]);
+                            if (bn) t = fmaf(fmaxf(t, 0.f), ss[k], tt[k]);
+                            v[k] = t;
+                        }
+                        uint2 ph, plo;
+                        lm_split4(v[0], v[1], v[2], v[3], &ph, &plo);
+                        lm_unsplit4(ph, plo, vv[mg]);
+                    }
+                    float best = 0.f;
+                    int arg = 0;
+                    for (int c = 0; c < p.head_C; ++c) {
+                        float sq[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const float4 w4 = *reinterpret_cast<const float4*>(&hw[c * 64 + 8 * q + 4 * kb]);
+                            // chain from 0: right for the kb = 0 lanes ...
+                            float s0 = fmaf(vv[q][0], w4.x, 0.f);
+                            s0 = fmaf(vv[q][1], w4.y, s0);
+                            s0 = fmaf(vv[q][2], w4.z, s0);
+                            s0 = fmaf(vv[q][3], w4.w, s0);
+                            // ... continued by the kb = 1 lane of the pixel from its partner's partial sum
+                            float s1 = __shfl_xor(s0, 32);
+                            s1 = fmaf(vv[q][0], w4.x, s1);
+                            s1 = fmaf(vv[q][1], w4.y, s1);
+                            s1 = fmaf(vv[q][2], w4.z, s1);
+                            s1 = fmaf(vv[q][3], w4.w, s1);
+                            sq[q] = s1;
+                        }
+                        const float lg = (((sq[0] + sq[4]) + (sq[2] + sq[6])) + ((sq[1] + sq[5]) + (sq[3] + sq[7]))) + hw[kMaxClasses * 64 + c];
+                        if (c == 0 || lg > best) {
+                            best = lg;
+                            arg = c;
+                        }
+                    }
+                    if (tile_ok && kb == 1) p.head_labels[((size_t)bs * p.H + yl) * p.W + x0 + li] = (uint8_t)arg;
+                }
+            } else {
             float pl[8][4];  // G32: row yb + row yb+1 (for the pool)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
@@ -499,6 +567,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                     if ((li & 1) == 0 && yb + 1 < p.H) split_store4(prow + (size_t)(cg >> 3) * 32, (cg & 7) * 2, q[0], q[1], q[2], q[3]);
                 }
             }
+            }  // stored-output epilogue
         }
         if (!have_next) break;
         it = nit;
@@ -547,7 +616,22 @@ static hipError_t launch_conv_h3_t(const ConvParamsH3& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_conv3x3_h3(const ConvParamsH3& p, hipStream_t stream) { return launch_conv_h3_t<9>(p, stream); }
+static bool h3_persistent_ok(const ConvParamsH3& p, int taps) {
+    static const bool wide_ok = [] { const char* e = getenv("LM_H3_FALLBACK"); return !(e && e[0] == '1'); }();
+    return wide_ok && (p.W % 32 == 0 || p.W == 16) && (size_t)2 * p.H * p.W * p.in_cstride * 4 < 0x7fffffffull &&
+           (size_t)taps * p.Cout * p.Cin * 4 < 0x7fffffffull;
+}
+
+bool conv3x3_h3_can_fuse_head(const ConvParamsH3& p) {
+    static const bool allow = [] { const char* e = getenv("LM_H3_FUSE_HEAD"); return !(e && e[0] == '0'); }();  // A/B hook
+    return allow && p.Cout == TN && p.W % 32 == 0 && h3_persistent_ok(p, 9);
+}
+
+hipError_t launch_conv3x3_h3(const ConvParamsH3& p, hipStream_t stream) {
+    if (p.head_labels != nullptr && (!conv3x3_h3_can_fuse_head(p) || p.head_C < 1 || p.head_C > kMaxClasses || !p.head_w || !p.head_b))
+        return hipErrorInvalidValue;
+    return launch_conv_h3_t<9>(p, stream);
+}
 hipError_t launch_conv1x1_h3(const ConvParamsH3& p, hipStream_t stream) { return launch_conv_h3_t<1>(p, stream); }
 
 // ---------------------------------------------------------------------------------------------

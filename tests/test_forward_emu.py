@@ -33,3 +33,15 @@ def test_forward_emulated_split_f16(emu_engine, golden_dir):
     assert np.abs(logp - g["rand32_logp"][:1]).max() < TOL
     bad = lab != g["rand32_lab"][:1]
     assert not np.any(bad & (g["rand32_margin"][:1].astype(np.float32) > 2 * TOL))
+
+
+def test_fused_head_is_bit_identical_to_the_head_kernel(emu_engine, golden_dir):
+    """Labels-only forwards run the head (1x1 conv + argmax) inside the last conv's epilogue; with log-probs requested the
+    separate head kernel runs on the stored output.  Same summation order by construction: identical labels."""
+    g = np.load(os.path.join(golden_dir, "unet_c6.npz"))
+    for c in (3, 6):
+        emu_engine.load_state_dict(0, uo.synthetic_state_dict(c))
+        x = g["rand32_x"][:1]
+        lab_fused = emu_engine.forward(0, x, want_logp=False)[0]
+        lab_plain, logp = emu_engine.forward(0, x)
+        assert np.array_equal(lab_fused, lab_plain) and np.array_equal(lab_plain, logp.argmax(1))

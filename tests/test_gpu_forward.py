@@ -164,3 +164,16 @@ def test_forward_work_item_orders_agree(order):
     mine = e.forward(0, np.random.default_rng(4).random((3, 256, 256), dtype=np.float32), want_logp=False)[0]
     e.close()
     assert np.array_equal(lab, mine)  # the order changes nothing but the schedule: bit-identical labels
+
+
+def test_fused_head_is_bit_identical_to_the_head_kernel(gpu_engine):
+    """Labels-only forwards (the production path) run the head inside the last conv's epilogue; with log-probs requested
+    the separate head kernel runs on the stored tensor.  Identical labels, also at the image border and for 6 classes."""
+    rng = np.random.default_rng(21)
+    for c, shape in ((3, (3, 256, 256)), (6, (2, 256, 256)), (3, (2, 64, 96))):
+        gpu_engine.load_state_dict(0, uo.synthetic_state_dict(c))
+        x = rng.random(shape, dtype=np.float32)
+        lab_fused = gpu_engine.forward(0, x, want_logp=False)[0]
+        lab_plain, logp = gpu_engine.forward(0, x)
+        assert np.array_equal(lab_fused, lab_plain), int((lab_fused != lab_plain).sum())
+        assert np.array_equal(lab_plain, logp.argmax(1))
