@@ -476,10 +476,15 @@ int forward_batches(lm_engine* e, int slot, const float* x, int n, int H, int W,
         LM_HIP(hipEventRecord(e->ev_fork, e->stream));
         LM_HIP(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
     }
+    // With two lanes and an odd number of batches the last batch would run alone (at the single-lane rate): it is cut in
+    // two halves, one per lane.  (Results do not depend on how slices are batched: every slice is computed on its own.)
+    const int n_batches = (n + batch - 1) / batch;
     int k = 0;
-    for (int b0 = 0; b0 < n; b0 += batch, ++k) {
-        const int b = std::min(batch, n - b0);
+    for (int b0 = 0; b0 < n; ++k) {
+        int b = std::min(batch, n - b0);
+        if (dual && (n_batches & 1) && b0 + b >= n && k == n_batches - 1 && b >= 2) b = (b + 1) / 2;
         LM_TRY(forward(e, slot, x + (size_t)b0 * px, b, H, W, labels + (size_t)b0 * px, nullptr, dual ? (k & 1) : 0));
+        b0 += b;
     }
     if (dual) {
         LM_HIP(hipEventRecord(e->ev_join, e->stream2));
