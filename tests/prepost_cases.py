@@ -160,6 +160,17 @@ def check_slab_postprocess(engines, shapes=((9, 24, 20), (5, 16, 16)), seeds=ran
             assert np.array_equal(out, ref), (world, int((out != ref).sum()))
             n_checked += 1
     assert po.postprocessing(lab.copy())[3, 5, 5] == 1 and po.postprocessing(lab2.copy())[3, 5, 5] == 0
+    # nothing at all (no atoms, no labels: every exchange is empty), and foreground confined to ONE slab
+    empty = np.zeros((6, 10, 10), np.uint8)
+    single = empty.copy()
+    single[4, 2:8, 2:8] = 2
+    single[4, 4:6, 4:6] = 0
+    for v in (empty, single):
+        ref = po.postprocessing(v.copy())
+        for world in range(2, len(engines) + 1):
+            out = postprocess_slabs_in_process(engines[:world], v, shard_bounds(6, world))
+            assert np.array_equal(out, ref), (world, int((out != ref).sum()))
+            n_checked += 1
     g = np.load(GOLD)
     for i in range(int(g["n_post"])):
         lab = g[f"post{i}_lab"]
