@@ -156,7 +156,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    eng.profile(True)
+    eng.profile(3)  # HIP events around the dominant kernel's launches only (events around every launch cost ~1 %)
     eng.profile_reset()
     sync_all()
     t0 = time.perf_counter()
@@ -171,18 +171,19 @@ def main():
     stats = eng.profile_read()
     eng.profile(False)
     post_info = eng.postprocess_info()
-    # One extra, untimed pass with a single forward lane: the dominant kernel's duration when it has the GPU
-    # to itself (in the timed region two batches' kernels overlap on two streams, which inflates per-kernel times).
-    solo = None
-    if world == 1 and args.streams == 2:
-        eng.set_streams(1)
-        eng.profile(True)
-        eng.profile_reset()
-        step()
-        eng.sync()
-        solo = eng.profile_read()
-        eng.profile(False)
-        eng.set_streams(2)
+    # One extra, untimed pass with a single forward lane and events around EVERY launch: the per-stage table, and the
+    # dominant kernel's duration when it has the GPU to itself (in the timed region two batches' kernels overlap on two
+    # streams, which inflates per-kernel times).  Every rank runs it (the multi-GPU step contains collectives).
+    eng.set_streams(1)
+    eng.profile(True)
+    eng.profile_reset()
+    step()
+    sync_all()
+    solo = eng.profile_read()
+    eng.profile(False)
+    eng.set_streams(args.streams)
+    if args.streams == 1:
+        stats = stats or solo
 
     if rank == 0:
         value = n_total * args.steps / dt
@@ -191,7 +192,7 @@ def main():
         conv = next((s for s in stats if s["name"] == kname), None)
         roof = None
         overlapped = None
-        if conv and conv["total_ms"] > 0 and solo:
+        if conv and conv["total_ms"] > 0 and solo and args.streams > 1:
             sc = next((s for s in solo if s["name"] == kname), None)
             if sc and sc["total_ms"] > 0:
                 overlapped = {"achieved": round(conv["flops"] / (conv["total_ms"] * 1e-3) / 1e12, 2),
@@ -245,7 +246,8 @@ def main():
             },
             "end_to_end_tflops": round(value * FLOP_PER_SLICE / 1e12, 2),
             "roofline": roof,
-            "stages_ms_per_step": {s["name"]: round(s["total_ms"] / args.steps, 3) for s in stats},
+            "stages_ms_per_step": {s["name"]: round(s["total_ms"], 3) for s in solo},
+            "stages_note": "HIP-event time per kernel kind of ONE step, from the untimed single-lane pass after the timed region",
             "postprocessing": post_info,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -153,9 +153,10 @@ int lm_forward_batches_dev(lm_engine* e, int slot, const float* x_dev, int n, in
                            uint8_t* labels_dev);
 int lm_set_streams(lm_engine* e, int n);
 
-/* Per-kernel timing of the network launches since the last reset (HIP events on
- * the engine stream; enabled with lm_profile_enable(e, 1)).  Returns the number
- * of distinct kernel kinds; fills up to `cap` entries. */
+/* Per-kernel timing of the launches since the last reset (HIP events on the launching stream).
+ * lm_profile_enable(e, on): 0 off; 1 every kernel; 2 every kernel, one entry per conv layer shape;
+ * 3 the dominant kernel (conv3x3) only -- a third of the events, for timed regions (the events of mode 1 cost ~1 %).
+ * lm_profile_read returns the number of distinct kernel kinds and fills up to `cap` entries. */
 typedef struct lm_kernel_stat {
     char name[48];
     int64_t launches;

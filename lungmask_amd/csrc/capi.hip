@@ -332,6 +332,7 @@ int lm_profile_enable(lm_engine* e, int on) {
     if (!e) return LM_ERR_INVALID;
     e->prof.on = on != 0;
     e->prof.per_layer = on == 2;
+    e->prof.dominant_only = on == 3;
     return LM_OK;
 }
 int lm_profile_reset(lm_engine* e) {

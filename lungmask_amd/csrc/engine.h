@@ -62,6 +62,8 @@ struct Model {
 struct Profiler {
     bool on = false;
     bool per_layer = false;  // lm_profile_enable(e, 2): one entry per conv shape instead of per kernel
+    bool dominant_only = false;  // lm_profile_enable(e, 3): events around the conv3x3 launches only (bench.py's timed region)
+    bool skipped = false;
     struct Rec {
         int kind;
         hipEvent_t a, b;

@@ -82,13 +82,18 @@ hipEvent_t Profiler::get_event() {
     return e;
 }
 void Profiler::begin(hipStream_t s, int kind, double flops, double bytes) {
+    skipped = false;
     if (!on) return;
+    if (dominant_only && names[kind].compare(0, 7, "conv3x3") != 0) {
+        skipped = true;
+        return;
+    }
     Rec r{kind, get_event(), get_event(), flops, bytes};
     (void)hipEventRecord(r.a, s);
     recs.push_back(r);
 }
 void Profiler::end(hipStream_t s) {
-    if (!on) return;
+    if (!on || skipped) return;
     (void)hipEventRecord(recs.back().b, s);
 }
 void Profiler::collect() {
