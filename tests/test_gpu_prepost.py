@@ -43,6 +43,13 @@ def test_empty_inputs(gpu_engine):
     assert gpu_engine.apply(0, np.zeros((0, 512, 512), np.int16)).shape == (0, 512, 512)
 
 
+def test_reference_utils_tests(gpu_engine):
+    """tests/test_utils.py of the reference, through the `lungmask_amd.utils` mirror."""
+    from reference_utils_cases import check_reference_utils_tests
+
+    check_reference_utils_tests(gpu_engine)
+
+
 def test_fusion(gpu_engine):
     cases.check_fuse(gpu_engine)
 

@@ -31,6 +31,14 @@ def test_empty_inputs_emulated(emu_engine):
     cases.check_empty_inputs(emu_engine)
 
 
+def test_reference_utils_tests_emulated(emu_engine):
+    """The reference's own tests of utils.preprocess / simple_bodymask / crop_and_resize / reshape_mask / postprocessing,
+    through the `lungmask_amd.utils` mirror."""
+    from reference_utils_cases import check_reference_utils_tests
+
+    check_reference_utils_tests(emu_engine)
+
+
 def test_fusion_emulated(emu_engine):
     cases.check_fuse(emu_engine)
 
