@@ -286,3 +286,32 @@ def test_two_engine_handles_from_two_threads(gpu_engine):
     for i in range(2):
         for k in range(2):
             assert np.array_equal(got[i][k], expect[(k + i) % 2]), (i, k)
+
+
+def test_lminferer_fused_and_deprecated_shims(gpu_engine, tmp_path, monkeypatch):
+    """tests/test_mask.py:50-59 (LMInferer(fillmodel=...)) and the deprecated module-level `apply` / `apply_fused`
+    (mask.py:235-279), offline: the weight files are seeded stand-ins under $LUNGMASK_WEIGHTS_DIR with the names of
+    the reference's download URLs."""
+    from lungmask_amd import mask as lm_mask
+
+    sd6, sd3 = uo.synthetic_state_dict(6), uo.synthetic_state_dict(3)
+    torch.save(sd6, tmp_path / "unet_ltrclobes-3a07043d.pth")
+    torch.save(sd3, tmp_path / "unet_r231-d5d2fc3d.pth")
+    monkeypatch.setenv("LUNGMASK_WEIGHTS_DIR", str(tmp_path))
+    vol = po.phantom(4, 512, 512, seed=81)
+    gpu_engine.load_state_dict(0, sd6)
+    gpu_engine.load_state_dict(1, sd3)
+    expect_fused = gpu_engine.apply(0, vol, fill_slot=1)
+    gpu_engine.load_state_dict(0, sd3)
+    expect_r231 = gpu_engine.apply(0, vol)
+    inferer = lm_mask.LMInferer(modelname="LTRCLobes", fillmodel="R231", tqdm_disable=True)
+    res = inferer.apply(vol)
+    assert res.dtype == np.uint8 and np.array_equal(res, expect_fused) and res.max() <= 6
+    with pytest.warns(DeprecationWarning):
+        assert np.array_equal(lm_mask.apply(vol), expect_r231)
+    with pytest.warns(DeprecationWarning):
+        assert np.array_equal(lm_mask.apply(vol, model=sd3), expect_r231)
+    with pytest.warns(DeprecationWarning):
+        assert np.array_equal(lm_mask.apply_fused(vol), expect_fused)
+    with pytest.raises(AssertionError):
+        lm_mask.LMInferer(modelname="R231", fillmodel="nope")
