@@ -200,15 +200,16 @@ int load_conv(Model& md, const TensorMap& tm, const std::string& conv, const std
     LM_TRY(upload(md, pw, &L->w));
     LM_TRY(upload(md, std::vector<float>(b->data, b->data + cout), &L->bias));
     if (cin % 8 == 0) {  // split-f16 packing: [tap][cout][cin/8 groups][8 hi | 8 lo] of w' = w * 2^k, lo = f16(w' - hi)
-        // k: the layer's largest |w'| lands in [8, 16), so the remainders of all but the tiniest weights are NORMAL f16
-        // numbers (full 11-bit precision of lo -> 2^-22 relative on w); 2^-k goes back in through the epilogue.
+        // k: the layer's largest |w'| lands in [1024, 2048) (a factor 32 below the f16 maximum), so the remainder of every
+        // weight down to 2^-14 of the largest one is a NORMAL f16 number (full 11-bit precision of lo -> 2^-22 relative on
+        // w, also for heavy-tailed trained weights); 2^-k goes back in through the epilogue.
         float wmax = 0.f;
         for (size_t j = 0; j < (size_t)taps * cout * cin; ++j) wmax = std::max(wmax, std::fabs(w->data[j]));
         int k = 0;
         if (wmax > 0.f && std::isfinite(wmax)) {
             int e = 0;
             (void)std::frexp(wmax, &e);  // wmax = m * 2^e, m in [0.5, 1)
-            k = 4 - e;                   // wmax * 2^k in [8, 16)
+            k = 11 - e;                  // wmax * 2^k in [1024, 2048)
         }
         const float up = std::ldexp(1.f, k);
         L->h3_acc_scale = std::ldexp(1.f, -k);

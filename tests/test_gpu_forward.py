@@ -177,3 +177,24 @@ def test_fused_head_is_bit_identical_to_the_head_kernel(gpu_engine):
         lab_plain, logp = gpu_engine.forward(0, x)
         assert np.array_equal(lab_fused, lab_plain), int((lab_fused != lab_plain).sum())
         assert np.array_equal(lab_plain, logp.argmax(1))
+
+
+def test_forward_heavy_tailed_weights(gpu_engine):
+    """Trained weights are heavy-tailed.  The split-f16 packing scales each layer by a power of two so that the f16
+    remainder (`lo`) of every weight down to 2^-14 of the layer's largest one stays a normal number: a layer whose largest
+    weight is 60x its typical ones must keep fp32-class accuracy (tolerance scaled with the logit range it produces)."""
+    sd = uo.synthetic_state_dict(3)
+    g = torch.Generator().manual_seed(5)
+    for k, v in sd.items():
+        if k.endswith(".weight") and v.ndim == 4 and v.shape[-1] == 3 and v.shape[1] >= 64:
+            mask = torch.rand(v.shape, generator=g) < 5e-4
+            sd[k] = torch.where(mask, v * 60.0, v)
+    gpu_engine.load_state_dict(0, sd)
+    x = np.random.default_rng(8).random((2, 256, 256), dtype=np.float32)
+    lab, logp = gpu_engine.forward(0, x)
+    ref = uo.forward(sd, torch.from_numpy(x[:, None])).numpy()
+    scale = max(1.0, float(np.abs(ref).max()) / 25.0)
+    err = float(np.abs(logp - ref).max())
+    assert err < TOL * scale, (err, scale)
+    margin = np.sort(ref, axis=1)[:, -1] - np.sort(ref, axis=1)[:, -2]
+    assert not np.any((lab != ref.argmax(1)) & (margin > 2 * TOL * scale))
