@@ -259,6 +259,12 @@ template <int TAPS, bool G16>
 __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptiles, int n_items, int xcd_order) {
     using SM = H3WSmem<TAPS, G16>;
     constexpr int HALO = SM::HALO, PW = SM::PW, TWW = SM::TWW, NW = SM::NW, ROWB = PW * 64, NTSTEP = SM::NTSTEP;
+    // Bank swizzle of the activation tile: 16-byte slot ^= (halo column >> ASWZ) & 3.  A ds_read_b128 lane group of 16
+    // lanes spans 16 consecutive-ish columns of ONE row in the 32-wide geometry (>> 2 is conflict free for all three dx)
+    // but 8 + 8 columns of TWO rows in the 16-wide one, where the 18-pixel halo rows lie half the banks apart: there >> 1
+    // is the conflict-free choice (enumerated over lane groups x dx x hi/lo; with >> 2 SQ_LDS_BANK_CONFLICT was 23 % of
+    // the LDS cycles, now 1 %).  The 1x1 form has no halo (rows a whole number of bank sets apart): >> 2 for both widths.
+    constexpr int ASWZ = (G16 && TAPS == 9) ? 1 : 2;
     constexpr int PSTR = 272;                   // staged pixel stride of the epilogue: 256 B of split data + 16 B pad
     constexpr int STAGE_BYTES = NW * 32 * PSTR;  // one 32-pixel row per wave
     // The epilogue staging area reuses the DMA buffer of the last chunk when it fits (3x3: 75 KiB), else it is extra.
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
 #pragma unroll
     for (int dx = 0; dx < (TAPS == 9 ? 3 : 1); ++dx) {
         const int px = wcol + dx;
-        a_off[dx] = (wsl * SM::SL_ROWS + wrow * PW + px) * 64 + ((2 * kb) ^ ((px >> 2) & 3)) * 16;
+        a_off[dx] = (wsl * SM::SL_ROWS + wrow * PW + px) * 64 + ((2 * kb) ^ ((px >> ASWZ) & 3)) * 16;
     }
     const int w_off = SM::A_BYTES + li * 64 + ((2 * kb) ^ ((li >> 2) & 3)) * 16;  // second M-tile: +2048
     const int w_off_lo = w_off ^ 16;
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
             const int row = idx >> 2;
             const int sl = row / SM::SL_ROWS, rr = row - sl * SM::SL_ROWS;
             const int py = rr / PW, px = rr - py * PW;
-            const int ls = (idx & 3) ^ ((px >> 2) & 3);
+            const int ls = (idx & 3) ^ ((px >> ASWZ) & 3);
             relA[j] = (unsigned)(((sl * p.H + py) * p.W + px) * p.in_cstride * 4 + (ls >> 1) * 32 + (ls & 1) * 16);
             pyx[j] = py | (px << 8) | (sl << 16);
         }
