@@ -255,6 +255,46 @@ __device__ __forceinline__ float4 as_float4(const lm_h16x8& v) {
         accm[1][1] = lm_mfma_f32_32x32x16_f16(f[3], f[6], accm[1][1]);                        \
     } while (0)
 
+// Software-pipelined form of the nine taps (LM_H3P_PIPE): the fragment reads of tap t+1 are in flight while the MFMAs of
+// tap t run (two fragment sets = 64 registers, affordable since the split scheme accumulates into one register set).
+#define H3P_READS(F, DY, DX)                                                                  \
+    do {                                                                                      \
+        const int a_lo_ = a_off[DX] ^ 16;                                                     \
+        LM_LDS_READ128(F[4], as + a_off[DX], (DY) * ROWB);                                    \
+        LM_LDS_READ128(F[5], as + a_lo_, (DY) * ROWB);                                        \
+        LM_LDS_READ128(F[6], as + a_off[DX], ((DY) + NTSTEP) * ROWB);                         \
+        LM_LDS_READ128(F[7], as + a_lo_, ((DY) + NTSTEP) * ROWB);                             \
+        LM_LDS_READ128(F[0], as + w_off, (3 * (DY) + (DX)) * (TN * 64));                      \
+        LM_LDS_READ128(F[1], as + w_off, (3 * (DY) + (DX)) * (TN * 64) + 2048);               \
+        LM_LDS_READ128(F[2], as + w_off_lo, (3 * (DY) + (DX)) * (TN * 64));                   \
+        LM_LDS_READ128(F[3], as + w_off_lo, (3 * (DY) + (DX)) * (TN * 64) + 2048);            \
+    } while (0)
+#define H3P_MFMAS(F)                                                                          \
+    do {                                                                                      \
+        accm[0][0] = lm_mfma_f32_32x32x16_f16(F[0], F[4], accm[0][0]);                        \
+        accm[0][1] = lm_mfma_f32_32x32x16_f16(F[0], F[6], accm[0][1]);                        \
+        accm[1][0] = lm_mfma_f32_32x32x16_f16(F[1], F[4], accm[1][0]);                        \
+        accm[1][1] = lm_mfma_f32_32x32x16_f16(F[1], F[6], accm[1][1]);                        \
+        accm[0][0] = lm_mfma_f32_32x32x16_f16(F[0], F[5], accm[0][0]);                        \
+        accm[0][1] = lm_mfma_f32_32x32x16_f16(F[0], F[7], accm[0][1]);                        \
+        accm[1][0] = lm_mfma_f32_32x32x16_f16(F[1], F[5], accm[1][0]);                        \
+        accm[1][1] = lm_mfma_f32_32x32x16_f16(F[1], F[7], accm[1][1]);                        \
+        accm[0][0] = lm_mfma_f32_32x32x16_f16(F[2], F[4], accm[0][0]);                        \
+        accm[0][1] = lm_mfma_f32_32x32x16_f16(F[2], F[6], accm[0][1]);                        \
+        accm[1][0] = lm_mfma_f32_32x32x16_f16(F[3], F[4], accm[1][0]);                        \
+        accm[1][1] = lm_mfma_f32_32x32x16_f16(F[3], F[6], accm[1][1]);                        \
+    } while (0)
+#define H3P_WAITF(N, F) LM_LDS_WAIT8(N, F[0], F[1], F[2], F[3], F[4], F[5], F[6], F[7])
+#define H3P_STEP(FC, FN, NDY, NDX) \
+    do {                           \
+        H3P_READS(FN, NDY, NDX);   \
+        H3P_WAITF(8, FC);          \
+        H3P_MFMAS(FC);             \
+    } while (0)
+#ifndef LM_H3P_PIPE
+#define LM_H3P_PIPE 1
+#endif
+
 template <int TAPS, bool G16>
 __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptiles, int n_items, int xcd_order) {
     using SM = H3WSmem<TAPS, G16>;
@@ -420,7 +460,14 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
             else if (have_next) issue(nb, ny0, nx0, nn0, 0, par ^ 1, true, epar ^ 1);
             const char* as = lds + par * SM::BUF_BYTES;
             lm_h16x8 f[8];  // whi0 whi1 wlo0 wlo1 a0hi a0lo a1hi a1lo
-            if (TAPS == 9) {
+            if (TAPS == 9 && LM_H3P_PIPE) {
+                lm_h16x8 g[8];
+                H3P_READS(f, 0, 0);
+                H3P_STEP(f, g, 0, 1); H3P_STEP(g, f, 0, 2); H3P_STEP(f, g, 1, 0); H3P_STEP(g, f, 1, 1);
+                H3P_STEP(f, g, 1, 2); H3P_STEP(g, f, 2, 0); H3P_STEP(f, g, 2, 1); H3P_STEP(g, f, 2, 2);
+                H3P_WAITF(0, f);
+                H3P_MFMAS(f);
+            } else if (TAPS == 9) {
                 H3P_TAP(0, 0); H3P_TAP(0, 1); H3P_TAP(0, 2);
                 H3P_TAP(1, 0); H3P_TAP(1, 1); H3P_TAP(1, 2);
                 H3P_TAP(2, 0); H3P_TAP(2, 1); H3P_TAP(2, 2);
