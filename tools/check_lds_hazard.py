@@ -29,59 +29,109 @@ def regs(tok):
 
 bad = 0
 checked = 0
+
+
+def successors(blk_lines, nxt):
+    """labels this block can continue to (branch targets + fallthrough)."""
+    out = []
+    falls = True
+    for ln in blk_lines:
+        op, _, rest = ln.lstrip("@").partition(" ")
+        if op.startswith("s_cbranch"):
+            out.append(rest.strip())
+        elif op == "s_branch":
+            out.append(rest.strip())
+            falls = False
+        elif op in ("s_endpgm", "s_setpc_b64"):
+            falls = False
+    if falls and nxt is not None:
+        out.append(nxt)
+    return out
+
+
 for km in re.finditer(r"^(_ZN2lm14conv_igemm_h3pI[^:\n]*):[^\n]*\n(.*?)^\s*s_endpgm", asm, re.S | re.M):
     name, body = km.group(1), km.group(2)
-    # basic blocks; only those with matrix instructions carry the hand-issued reads (elsewhere every LDS read is the
-    # compiler's own and its waitcnt pass -- which also counts scalar loads in lgkmcnt -- takes care of it)
-    blocks, cur = [], []
-    for ln in body.splitlines():
-        ln = ln.split(";")[0].strip()
+    order, blocks, cur = ["<entry>"], {"<entry>": []}, "<entry>"
+    in_asm = False
+    for raw in body.splitlines():
+        if "#ASMSTART" in raw:
+            in_asm = True
+            continue
+        if "#ASMEND" in raw:
+            in_asm = False
+            continue
+        ln = raw.split(";")[0].strip()
         if not ln:
             continue
-        if re.match(r"^\.?LBB\d+_\d+:", ln) or ln.endswith(":"):
-            blocks.append(cur)
-            cur = []
+        if in_asm:
+            ln = "@" + ln  # hand-issued (inline asm) instruction
+        m = re.match(r"^(\.?LBB\d+_\d+):", ln)
+        if m:
+            cur = m.group(1)
+            order.append(cur)
+            blocks[cur] = []
             continue
-        cur.append(ln)
-    blocks.append(cur)
-    for blk in blocks:
-        if not any(l.startswith("v_mfma") for l in blk):
+        if ln.endswith(":"):
             continue
-        pending = []  # FIFO of destination register sets (LDS returns are in order)
-        for ln in blk:
+        blocks[cur].append(ln)
+    succ = {lab: successors(blocks[lab], order[i + 1] if i + 1 < len(order) else None) for i, lab in enumerate(order)}
+    has_mfma = {lab: any(l.lstrip("@").startswith("v_mfma") for l in blocks[lab]) for lab in order}
+
+    def run(lab, pending):
+        """replay one block from the in-flight FIFO `pending`; returns the FIFO at its end"""
+        global bad, checked
+        pending = [set(x) for x in pending]
+        for ln in blocks[lab]:
+            hand = ln.startswith("@")
+            ln = ln.lstrip("@")
             op, _, rest = ln.partition(" ")
             toks = [t.strip() for t in rest.split(",")] if rest else []
-            if op == "ds_read_b128":
+            if op == "ds_read_b128" and hand:  # the compiler's own LDS reads are covered by its waitcnt pass
                 dst = regs(toks[0])
-                for pset in pending:
-                    if pset & dst:
-                        print(f"{name}: ds_read_b128 overwrites a pending destination: {ln}")
-                        bad += 1
+                if any(pset & dst for pset in pending):
+                    print(f"{name}/{lab}: ds_read_b128 overwrites a pending destination: {ln}")
+                    bad += 1
                 pending.append(dst)
-                checked += 1
                 continue
             if op == "s_waitcnt":
                 m = re.search(r"lgkmcnt\((\d+)\)", ln)
                 if m:
                     n = int(m.group(1))
-                    pending = pending[len(pending) - n:] if 0 < n < len(pending) else ([] if n == 0 else pending)
+                    if n == 0:
+                        pending = []
+                    elif hand and n < len(pending):  # LDS ops retire in order: a hand-placed counted wait leaves the newest n
+                        pending = pending[len(pending) - n:]
+                    # (a counted wait of the compiler is computed without our reads: conservatively retires nothing)
                 continue
-            if op.startswith("s_load") or op.startswith("s_buffer_load"):
-                print(f"{name}: scalar load inside a tap block (shares lgkmcnt with the LDS reads): {ln}")
+            if has_mfma[lab] and (op.startswith("s_load") or op.startswith("s_buffer_load")):
+                print(f"{name}/{lab}: scalar load inside a tap block (shares lgkmcnt with the LDS reads): {ln}")
                 bad += 1
             if not pending:
                 continue
             used = set()
             for t in toks:
                 used |= regs(t.split(" ")[0])
-            for pset in pending:
-                if pset & used:
-                    print(f"{name}: '{ln}' touches a register of an LDS read that is still in flight")
-                    bad += 1
-                    break
-        if pending:
-            print(f"{name}: {len(pending)} reads still in flight at the end of a tap block")
-            bad += 1
+            if any(pset & used for pset in pending):
+                print(f"{name}/{lab}: '{ln}' touches a register of an LDS read that is still in flight")
+                bad += 1
+        return pending
+
+    # forward propagation of the in-flight state along the control-flow graph, seeded at the hand-scheduled blocks
+    seen = set()
+    work = [(lab, ()) for lab in order if has_mfma[lab]]
+    while work:
+        lab, pend = work.pop()
+        key = (lab, tuple(tuple(sorted(x)) for x in pend))
+        if key in seen:
+            continue
+        seen.add(key)
+        out = run(lab, pend)
+        if out:
+            for nx in succ[lab]:
+                if nx in blocks:
+                    work.append((nx, tuple(frozenset(x) for x in out)))
+    checked += sum(1 for lab in order for l in blocks[lab] if l.startswith("@ds_read_b128"))
+
 # Second invariant: every workgroup barrier of these kernels publishes LDS-DMA data, so each wave must have drained its own
 # DMAs (s_waitcnt vmcnt(0)) after its last global_load_lds and before the s_barrier (hipcc once dropped that wait on one path).
 barriers = 0
@@ -102,5 +152,5 @@ for km in re.finditer(r"^(_ZN2lm14conv_igemm_h3pI[^:\n]*):[^\n]*\n(.*?)^\s*s_end
             print(f"{name}: s_barrier without a preceding s_waitcnt vmcnt(0)")
             bad += 1
 print(f"{barriers} barriers checked for the vmcnt(0) in front of them")
-print(f"{checked} hand-issued ds_read_b128 checked in the matrix blocks of the conv_igemm_h3p instantiations, {bad} hazards")
+print(f"{checked} hand-issued ds_read_b128 checked (in-flight state propagated along the control-flow graph), {bad} hazards")
 sys.exit(1 if bad else 0)
