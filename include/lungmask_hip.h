@@ -128,6 +128,9 @@ int lm_postprocess_dev(lm_engine* e, uint8_t* lab_dev, int n, int h, int w, cons
 int lm_slab_begin(lm_engine* e, uint8_t* lab_slab_dev, int n, int h, int w, int rank, int world, int z0, int n_total,
                   const int* spare, int n_spare, int skip_below);
 int64_t lm_slab_pending(lm_engine* e);
+/* 1 when the pending length is the same on every rank by construction (the face-plane exchanges): the caller may skip
+ * the all-gather of the lengths for this round. */
+int lm_slab_pending_uniform(lm_engine* e);
 int lm_slab_emit(lm_engine* e, int32_t* dst_dev);
 int lm_slab_step(lm_engine* e, const int32_t* gathered_dev, int64_t stride, const int64_t* lens);
 

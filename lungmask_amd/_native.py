@@ -73,6 +73,7 @@ class Library:
         L.lm_slab_begin.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.POINTER(C.c_int), C.c_int, C.c_int]
         L.lm_slab_pending.argtypes = [C.c_void_p]
         L.lm_slab_pending.restype = C.c_int64
+        L.lm_slab_pending_uniform.argtypes = [C.c_void_p]
         L.lm_slab_emit.argtypes = [C.c_void_p, C.c_void_p]
         L.lm_slab_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         L.lm_postprocess_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]

@@ -250,6 +250,8 @@ int lm_slab_begin(lm_engine* e, uint8_t* lab_slab_dev, int n, int h, int w, int 
 
 int64_t lm_slab_pending(lm_engine* e) { return (e && e->slab.phase >= 0) ? (int64_t)e->slab.pending : -1; }
 
+int lm_slab_pending_uniform(lm_engine* e) { return (e && e->slab.phase >= 0 && e->slab.pending_uniform) ? 1 : 0; }
+
 int lm_slab_emit(lm_engine* e, int32_t* dst_dev) {
     if (!e) return LM_ERR_INVALID;
     LM_DEVICE(e);

@@ -124,6 +124,7 @@ struct SlabState {
     std::vector<int> labels, n3;  // label values with a kept component; atoms of each label's background labelling
     DevBuf ids2, ids3, first, flags, edges, pack, keeplut, holelut;
     long long pending = 0;  // ints of `pack` this rank contributes to the next exchange
+    bool pending_uniform = false;  // the pending length is the same on every rank by construction (face planes)
     std::vector<std::vector<int>> tables;  // host copies of the gathered tables
     void release() {
         ids2.release(); ids3.release(); first.release(); flags.release(); edges.release(); pack.release(); keeplut.release(); holelut.release();

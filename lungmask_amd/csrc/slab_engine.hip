@@ -110,6 +110,7 @@ int pack_faces(lm_engine* e, const uint8_t* lab, const int* ids, Dims d) {
     LM_K(widen_u8(lab + last, pk + 2 * HW, HW, e->stream));
     LM_HIP(hipMemcpyAsync(pk + 3 * HW, ids + last, HW * 4, hipMemcpyDeviceToDevice, e->stream));
     st.pending = (long long)(4 * HW);
+    st.pending_uniform = true;
     return LM_OK;
 }
 
@@ -386,6 +387,7 @@ int pack_atom_table(lm_engine* e, int n, unsigned nrec, unsigned nedge) {
     if (nrec) LM_HIP(hipMemcpyAsync(pk + 4 + 3 * (size_t)n, ws.recs.p, (size_t)nrec * sizeof(BoundaryRec), hipMemcpyDeviceToDevice, e->stream));
     if (nedge) LM_HIP(hipMemcpyAsync(pk + 4 + 3 * (size_t)n + 8 * (size_t)nrec, st.edges.p, (size_t)nedge * 8, hipMemcpyDeviceToDevice, e->stream));
     st.pending = (long long)len;
+    st.pending_uniform = false;
     return LM_OK;
 }
 
@@ -556,6 +558,7 @@ int slab_step(lm_engine* e, const int32_t* gathered, long long stride, const lon
                 LM_HIP(hipMemcpyAsync(st.pack.as<int>() + (size_t)(2 * k + 1) * HW, ids3 + last, HW * 4, hipMemcpyDeviceToDevice, s));
             }
             st.pending = (long long)((size_t)K * 2 * HW);
+            st.pending_uniform = true;  // K is derived from the gathered tables: the same on every rank
             break;
         }
         case 4: {  // faces 3 -> table 3
@@ -593,6 +596,7 @@ int slab_step(lm_engine* e, const int32_t* gathered, long long stride, const lon
                 eoff += ne[k];
             }
             st.pending = (long long)len;
+            st.pending_uniform = false;
             break;
         }
         case 5: {  // table 3 -> holes; write the result

@@ -86,7 +86,9 @@ class ShardedPipeline:
             n = int(lib.lm_slab_pending(e.h))
             if n < 0:
                 raise RuntimeError("lm_slab_pending: no slab post-processing in progress")
-            if self.dist is not None:
+            if self.dist is not None and lib.lm_slab_pending_uniform(e.h):
+                lens = [n] * self.world  # face planes: the same length on every rank, no need to exchange it
+            elif self.dist is not None:
                 lens_t = self._tensor("slab_lens", (self.world,), torch.int64)
                 self._all_gather(lens_t, torch.tensor([n], dtype=torch.int64, device=self.device))
                 lens = [int(v) for v in lens_t.cpu().tolist()]
