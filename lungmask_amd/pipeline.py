@@ -104,6 +104,15 @@ class ShardedPipeline:
             if status == 1:
                 return
 
+    def apply(self, volume: np.ndarray) -> np.ndarray:
+        """Convenience form of `LMInferer.apply` for a process group: every rank passes the SAME host volume [n,h,w] (int16),
+        works on its own block of slices and returns the complete uint8 label volume."""
+        vol = np.ascontiguousarray(volume, dtype=np.int16)
+        n_total = int(vol.shape[0])
+        b = shard_bounds(n_total, self.world)
+        shard = torch.from_numpy(vol[b[self.rank] : b[self.rank + 1]]).to(self.device)
+        return self.apply_shard(shard.contiguous(), n_total).cpu().numpy()
+
     def shard_buffers(self, n_total: int):
         """(bounds, bbox [maxc,4] int32, lab_all [world*maxc,oh,ow] u8, lab_loc = this rank's part of lab_all)."""
         bounds = shard_bounds(n_total, self.world)

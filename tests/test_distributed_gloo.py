@@ -51,9 +51,8 @@ def _worker(rank, world, port, n_total, outdir, mode):
     if mode == "full":  # the whole sharded pipeline incl. the (emulated, slow) network
         eng.load_state_dict(0, uo.synthetic_state_dict(3))
         vol = po.phantom(n_total, 96, 80, seed=3)
-        shard = torch.from_numpy(vol[b[rank] : b[rank + 1]].copy())
         pipe = ShardedPipeline(eng, slot=0, batch_size=2, resolution=(32, 32), dist=dist, device="cpu")
-        np.save(os.path.join(outdir, f"out{rank}.npy"), pipe.apply_shard(shard, n_total).numpy().copy())
+        np.save(os.path.join(outdir, f"out{rank}.npy"), pipe.apply(vol))  # every rank passes the whole volume, works on its block
     else:  # everything after the argmax, on a structured label volume, in both post-processing forms
         lab, boxes = _labels_and_boxes(n_total, 32, (96, 80))
         for sharded in (True, False):
