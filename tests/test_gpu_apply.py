@@ -60,6 +60,14 @@ def test_apply_r231_phantom(gpu_engine):
     run_case(gpu_engine, uo.synthetic_state_dict(3), vol, batch=4)  # 6 slices, batch 4: ragged last batch
 
 
+@pytest.mark.parametrize("n_classes,n,z0", [(3, 40, 130), (6, 24, 140)])
+def test_apply_central_slices_of_the_bench_phantom(gpu_engine, n_classes, n, z0):
+    """The slices the benchmark actually spends its time on (lungs present, thousands of regions for the merge loop), two
+    full batches on two lanes: whole pipeline against the oracle."""
+    vol = po.phantom(300, 512, 512, seed=2024, z0=z0, z1=z0 + n)
+    run_case(gpu_engine, uo.synthetic_state_dict(n_classes), vol, batch=20)
+
+
 def test_apply_ltrclobes_phantom_odd_shape(gpu_engine):
     vol = po.phantom(5, 300, 420, seed=5)
     run_case(gpu_engine, uo.synthetic_state_dict(6), vol, batch=20)
