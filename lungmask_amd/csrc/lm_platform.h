@@ -95,6 +95,98 @@ __device__ __forceinline__ void lm_global_load_lds4(const void* gsrc, void* lds_
 #endif
 }
 
+// ---- buffer-descriptor LDS-DMA (buffer_load_dwordx4 ... offen lds) ---------------------------------------------
+// A raw buffer descriptor (base, num_records bytes): a lane whose voffset + soffset lies outside [0, num_records)
+// writes ZEROS to its 16 LDS bytes, so out-of-image halo pixels need neither branches nor a zero page: their lanes
+// carry voffset = LM_DMA_OOB.  The instruction is hand-issued (the compiler neither counts it in vmcnt nor drains it):
+// lm_dma_wait_all() + a barrier publish the data.  M0 (LDS destination = wave-uniform base + lane * 16) is written in
+// the same statement.
+#define LM_DMA_OOB 0x80000000u
+#ifdef LM_EMU_BUILD
+struct lm_rsrc {
+    const char* base;
+    unsigned bytes;
+};
+__device__ __forceinline__ lm_rsrc lm_make_rsrc(const void* base, size_t bytes) { return lm_rsrc{(const char*)base, (unsigned)bytes}; }
+__device__ __forceinline__ void lm_dma16(const lm_rsrc& r, unsigned voff, unsigned soff, void* lds_wave_base) {
+    char* d = (char*)lds_wave_base + (lm_emu::linear_tid() & 63) * 16;
+    const unsigned long long off = (unsigned long long)voff + soff;
+    if (off + 16 <= r.bytes) memcpy(d, r.base + off, 16);
+    else memset(d, 0, 16);
+}
+__device__ __forceinline__ void lm_dma4_global(const void* gsrc, void* lds_wave_base) {
+    memcpy((char*)lds_wave_base + (lm_emu::linear_tid() & 63) * 4, gsrc, 4);
+}
+__device__ __forceinline__ void lm_barrier_dma() { __syncthreads(); }
+__device__ __forceinline__ void lm_barrier_lds() { __syncthreads(); }
+#define LM_PIN(x) \
+    do {          \
+    } while (0)
+#else
+typedef int lm_rsrc __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ lm_rsrc lm_make_rsrc(const void* base, size_t bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    lm_rsrc r;
+    r[0] = (int)(unsigned)a;
+    r[1] = (int)(unsigned)(a >> 32);  // stride 0: raw buffer
+    r[2] = (int)(unsigned)bytes;
+    r[3] = 0x00020000;                // gfx9 raw-buffer dword 3 (DATA_FORMAT = 32)
+    return r;
+}
+__device__ __forceinline__ void lm_dma16(lm_rsrc r, unsigned voff, unsigned soff, void* lds_wave_base) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base), "v"(voff), "s"(r), "s"(soff)
+                 : "memory");
+}
+// 4-byte form on a flat pointer (global_load_lds_dword): 64 lanes fill 256 contiguous LDS bytes
+__device__ __forceinline__ void lm_dma4_global(const void* gsrc, void* lds_wave_base) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"
+                 :
+                 : "s"((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base), "v"(gsrc)
+                 : "memory");
+}
+// Workgroup barrier that publishes this wave's LDS-DMAs (and retires its hand-issued LDS reads) ...
+__device__ __forceinline__ void lm_barrier_dma() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// ... and one that only orders LDS accesses (no DMA of this wave may be needed by anyone after it): global stores stay in flight
+__device__ __forceinline__ void lm_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier ; LM_BARRIER_LDS_ONLY" ::: "memory"); }
+// Opaque use of a value: orders an asm statement against the instructions that produce / consume x
+#define LM_PIN(x) asm volatile("" : "+v"(x))
+#endif
+
+// ---- in-kernel cycle accounting of the persistent conv kernel (lab builds only: -DLM_H3_TRACE) ------------------
+// Per wave, the shader-clock cycles between consecutive marks are summed per category and written to lm_h3_trace_ptr
+// ([workgroup][wave][8] unsigned) at kernel end.  The product build compiles all of it to nothing.
+#if defined(LM_H3_TRACE) && !defined(LM_EMU_BUILD)
+extern __device__ unsigned* lm_h3_trace_ptr;
+#define LM_TRACE_INIT()                                     \
+    unsigned tr_last_ = (unsigned)__builtin_amdgcn_s_memtime(); \
+    unsigned tr_sum_[6] = {0u, 0u, 0u, 0u, 0u, 0u}
+#define LM_TRACE_MARK(K)                                              \
+    do {                                                              \
+        const unsigned n_ = (unsigned)__builtin_amdgcn_s_memtime();   \
+        tr_sum_[K] += n_ - tr_last_;                                  \
+        tr_last_ = n_;                                                \
+    } while (0)
+#define LM_TRACE_FLUSH()                                                                                   \
+    do {                                                                                                   \
+        if (lm_h3_trace_ptr && (threadIdx.x & 63) == 0) {                                                  \
+            unsigned* o_ = lm_h3_trace_ptr + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8;            \
+            for (int k_ = 0; k_ < 6; ++k_) o_[k_] = tr_sum_[k_];                                            \
+        }                                                                                                  \
+    } while (0)
+#else
+#define LM_TRACE_INIT() \
+    do {                \
+    } while (0)
+#define LM_TRACE_MARK(K) \
+    do {                 \
+    } while (0)
+#define LM_TRACE_FLUSH() \
+    do {                 \
+    } while (0)
+#endif
+
 // fp32 x4 -> split-f16: hi = f16(v), lo = f16(v - hi) (UNSCALED: for |v| < 2^-3 the remainder is an f16 denormal, which
 // conversions and the matrix instructions honour -- tools/ubench/mfma_denorm.hip -- so v = hi + lo to 2^-25 absolute or
 // 2^-22 relative, whichever is larger), each packed as 4 halves (8 bytes).

@@ -26,6 +26,10 @@
 
 #include "nn_kernels.h"
 
+#if defined(LM_H3_TRACE) && !defined(LM_EMU_BUILD)
+__device__ unsigned* lm_h3_trace_ptr = nullptr;
+#endif
+
 namespace lm {
 
 namespace {
@@ -191,15 +195,25 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(ConvParamsH3 p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Persistent variant for W % 32 == 0 (every level but the 16x16 bottleneck).
+// Persistent variant for W % 32 == 0 and the 16x16 bottleneck (second geometry).
 //
 // One 512-thread workgroup per CU (8 waves = 2 per SIMD, <= 256 VGPRs) walks a list of work items
-// (64 couts x 16 rows x 32 cols of one slice) and software-pipelines ACROSS items: LDS is double buffered
-// (2 x 75 KiB) and the LDS-DMA of the next 16-channel chunk -- of this item or the first chunk of the next
-// one -- is issued right after the single barrier of the current chunk, so neither the DMA latency nor the
-// workgroup start-up is exposed between tiles (measured: ~17 us per tile with one workgroup per tile).
-// Wave w = row pair w: both 32-cout M-tiles against two 32-pixel N-tiles (rows 2w, 2w+1), {main, corr}
-// accumulators = 128 registers; 8 fragment reads feed 12 MFMAs per tap.  Fragment reads are hand-issued ds_read_b128 with immediate
+// (64 couts x 16 rows x 32 cols of one slice) and software-pipelines ACROSS chunks and items:
+//   * LDS is double buffered (2 x 75 KiB); 16-channel chunk c of an item lives in buffer c & 1 (Cin/16 is even).
+//   * global -> LDS by buffer-descriptor LDS-DMA (lm_dma16): branch-free, out-of-image halo lanes carry an
+//     out-of-range offset and the hardware writes zeros.  Per item each lane's source offsets are computed ONCE
+//     (voff); per chunk a DMA piece is "set M0, issue" with the chunk offset in the scalar offset operand.
+//   * the nine taps of a chunk are a register pipeline (fragment reads of tap t+1 in flight under the MFMAs of tap
+//     t, two fragment sets) that runs THROUGH the chunk barrier: the single barrier of a chunk sits in front of
+//     the LAST tap's MFMAs (all of this wave's LDS reads of the chunk have returned; its DMAs of the next chunk
+//     have landed), the first fragment reads of the next chunk are issued right behind it, and the 12 MFMAs of the
+//     last tap cover barrier skew and read latency.  The DMA pieces of chunk c+2 (or of the next item's chunk 0)
+//     are issued one at a time between the MFMAs of the first three taps of chunk c+1.
+//   * an item ends with its epilogue (staged through the buffer of its last chunk); the next item's first chunk
+//     and epilogue constants are already resident.  The barrier behind the epilogue only orders LDS accesses
+//     (lm_barrier_lds): the epilogue's global stores stay in flight.
+// Wave w = row pair w: both 32-cout M-tiles against two 32-pixel N-tiles (rows 2w, 2w+1): 64 accumulator
+// registers; 8 fragment reads feed 12 MFMAs per tap.  Fragment reads are hand-issued ds_read_b128 with immediate
 // offsets (the bank swizzle depends on the halo COLUMN only, so tap shifts are plain byte offsets); both
 // fragment streams are bank-conflict free.  The 2x2 average pool is in-lane (two N-tiles) + one lane^1 exchange.
 namespace {
@@ -229,71 +243,84 @@ __device__ __forceinline__ float4 as_float4(const lm_h16x8& v) {
 }
 }  // namespace
 
-#define H3P_TAP(DY, DX)                                                                       \
-    do {                                                                                      \
+// Lab builds (tools/ubench/conv_lab.hip) can ablate one stream of the kernel to price it: -DLM_H3_ABLATE=1 issues no fragment
+// reads after an item's first chunk (the registers keep its operands), =2 stages nothing after an item's second chunk.
+#ifdef LM_H3_ABLATE
+#define LM_ABL_READS(ci) (LM_H3_ABLATE == 1 && (ci) > 0)
+#define LM_ABL_DMA(c0) (LM_H3_ABLATE == 2 && (c0) > KC)
+#else
+#define LM_ABL_READS(ci) false
+#define LM_ABL_DMA(c0) false
+#endif
+// fragment reads of tap (DY, DX) from the chunk buffer at AS into the set F: whi0 whi1 wlo0 wlo1 a0hi a0lo a1hi a1lo
+#define H3P_READS(F, AS, DY, DX)                                                              \
+    if (!abl_r) {                                                                             \
         const int a_lo_ = a_off[DX] ^ 16;                                                     \
-        LM_LDS_READ128(f[4], as + a_off[DX], (DY) * ROWB);                                    \
-        LM_LDS_READ128(f[5], as + a_lo_, (DY) * ROWB);                                        \
-        LM_LDS_READ128(f[6], as + a_off[DX], ((DY) + NTSTEP) * ROWB);                         \
-        LM_LDS_READ128(f[7], as + a_lo_, ((DY) + NTSTEP) * ROWB);                             \
-        LM_LDS_READ128(f[0], as + w_off, (3 * (DY) + (DX)) * (TN * 64));                      \
-        LM_LDS_READ128(f[1], as + w_off, (3 * (DY) + (DX)) * (TN * 64) + 2048);               \
-        LM_LDS_READ128(f[2], as + w_off_lo, (3 * (DY) + (DX)) * (TN * 64));                   \
-        LM_LDS_READ128(f[3], as + w_off_lo, (3 * (DY) + (DX)) * (TN * 64) + 2048);            \
-        LM_LDS_WAIT8(0, f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);                      \
-        accm[0][0] = lm_mfma_f32_32x32x16_f16(f[0], f[4], accm[0][0]);                        \
-        accm[0][1] = lm_mfma_f32_32x32x16_f16(f[0], f[6], accm[0][1]);                        \
-        accm[1][0] = lm_mfma_f32_32x32x16_f16(f[1], f[4], accm[1][0]);                        \
-        accm[1][1] = lm_mfma_f32_32x32x16_f16(f[1], f[6], accm[1][1]);                        \
-        accm[0][0] = lm_mfma_f32_32x32x16_f16(f[0], f[5], accm[0][0]);                        \
-        accm[0][1] = lm_mfma_f32_32x32x16_f16(f[0], f[7], accm[0][1]);                        \
-        accm[1][0] = lm_mfma_f32_32x32x16_f16(f[1], f[5], accm[1][0]);                        \
-        accm[1][1] = lm_mfma_f32_32x32x16_f16(f[1], f[7], accm[1][1]);                        \
-        accm[0][0] = lm_mfma_f32_32x32x16_f16(f[2], f[4], accm[0][0]);                        \
-        accm[0][1] = lm_mfma_f32_32x32x16_f16(f[2], f[6], accm[0][1]);                        \
-        accm[1][0] = lm_mfma_f32_32x32x16_f16(f[3], f[4], accm[1][0]);                        \
-        accm[1][1] = lm_mfma_f32_32x32x16_f16(f[3], f[6], accm[1][1]);                        \
-    } while (0)
-
-// Software-pipelined form of the nine taps (LM_H3P_PIPE): the fragment reads of tap t+1 are in flight while the MFMAs of
-// tap t run (two fragment sets = 64 registers, affordable since the split scheme accumulates into one register set).
-#define H3P_READS(F, DY, DX)                                                                  \
+        LM_LDS_READ128(F[4], (AS) + a_off[DX], (DY) * ROWB);                                  \
+        LM_LDS_READ128(F[5], (AS) + a_lo_, (DY) * ROWB);                                      \
+        LM_LDS_READ128(F[6], (AS) + a_off[DX], ((DY) + NTSTEP) * ROWB);                       \
+        LM_LDS_READ128(F[7], (AS) + a_lo_, ((DY) + NTSTEP) * ROWB);                           \
+        LM_LDS_READ128(F[0], (AS) + w_off, (3 * (DY) + (DX)) * (TN * 64));                    \
+        LM_LDS_READ128(F[1], (AS) + w_off, (3 * (DY) + (DX)) * (TN * 64) + 2048);             \
+        LM_LDS_READ128(F[2], (AS) + w_off_lo, (3 * (DY) + (DX)) * (TN * 64));                 \
+        LM_LDS_READ128(F[3], (AS) + w_off_lo, (3 * (DY) + (DX)) * (TN * 64) + 2048);          \
+    } else                                                                                    \
+        (void)0
+#define H3P_MFMA3(F, I0, I1, I2)                                                              \
     do {                                                                                      \
-        const int a_lo_ = a_off[DX] ^ 16;                                                     \
-        LM_LDS_READ128(F[4], as + a_off[DX], (DY) * ROWB);                                    \
-        LM_LDS_READ128(F[5], as + a_lo_, (DY) * ROWB);                                        \
-        LM_LDS_READ128(F[6], as + a_off[DX], ((DY) + NTSTEP) * ROWB);                         \
-        LM_LDS_READ128(F[7], as + a_lo_, ((DY) + NTSTEP) * ROWB);                             \
-        LM_LDS_READ128(F[0], as + w_off, (3 * (DY) + (DX)) * (TN * 64));                      \
-        LM_LDS_READ128(F[1], as + w_off, (3 * (DY) + (DX)) * (TN * 64) + 2048);               \
-        LM_LDS_READ128(F[2], as + w_off_lo, (3 * (DY) + (DX)) * (TN * 64));                   \
-        LM_LDS_READ128(F[3], as + w_off_lo, (3 * (DY) + (DX)) * (TN * 64) + 2048);            \
+        H3P_MFMA1(F, I0);                                                                     \
+        H3P_MFMA1(F, I1);                                                                     \
+        H3P_MFMA1(F, I2);                                                                     \
     } while (0)
-#define H3P_MFMAS(F)                                                                          \
-    do {                                                                                      \
-        accm[0][0] = lm_mfma_f32_32x32x16_f16(F[0], F[4], accm[0][0]);                        \
-        accm[0][1] = lm_mfma_f32_32x32x16_f16(F[0], F[6], accm[0][1]);                        \
-        accm[1][0] = lm_mfma_f32_32x32x16_f16(F[1], F[4], accm[1][0]);                        \
-        accm[1][1] = lm_mfma_f32_32x32x16_f16(F[1], F[6], accm[1][1]);                        \
-        accm[0][0] = lm_mfma_f32_32x32x16_f16(F[0], F[5], accm[0][0]);                        \
-        accm[0][1] = lm_mfma_f32_32x32x16_f16(F[0], F[7], accm[0][1]);                        \
-        accm[1][0] = lm_mfma_f32_32x32x16_f16(F[1], F[5], accm[1][0]);                        \
-        accm[1][1] = lm_mfma_f32_32x32x16_f16(F[1], F[7], accm[1][1]);                        \
-        accm[0][0] = lm_mfma_f32_32x32x16_f16(F[2], F[4], accm[0][0]);                        \
-        accm[0][1] = lm_mfma_f32_32x32x16_f16(F[2], F[6], accm[0][1]);                        \
-        accm[1][0] = lm_mfma_f32_32x32x16_f16(F[3], F[4], accm[1][0]);                        \
-        accm[1][1] = lm_mfma_f32_32x32x16_f16(F[3], F[6], accm[1][1]);                        \
+// the 12 matrix instructions of one tap, numbered 0..11: (M-tile, N-tile) fastest, then hi*hi, hi*lo, lo*hi
+#define H3P_MFMA1(F, I)                                                                                                           \
+    accm[((I) >> 1) & 1][(I) & 1] = lm_mfma_f32_32x32x16_f16(F[((I) < 8 ? 0 : 2) + (((I) >> 1) & 1)],                             \
+                                                            F[4 + 2 * ((I) & 1) + (((I) >> 2) == 1 ? 1 : 0)], accm[((I) >> 1) & 1][(I) & 1])
+#define H3P_MFMAS(F)             \
+    do {                         \
+        H3P_MFMA3(F, 0, 1, 2);   \
+        H3P_MFMA3(F, 3, 4, 5);   \
+        H3P_MFMA3(F, 6, 7, 8);   \
+        H3P_MFMA3(F, 9, 10, 11); \
+    } while (0)
+// the same with four DMA slots (K0 .. K0+3) spread between the matrix instructions
+#define H3P_MFMAS_D(F, K0)       \
+    do {                         \
+        H3P_MFMA3(F, 0, 1, 2);   \
+        dma_slot((K0) + 0);      \
+        H3P_MFMA3(F, 3, 4, 5);   \
+        dma_slot((K0) + 1);      \
+        H3P_MFMA3(F, 6, 7, 8);   \
+        dma_slot((K0) + 2);      \
+        H3P_MFMA3(F, 9, 10, 11); \
+        dma_slot((K0) + 3);      \
     } while (0)
 #define H3P_WAITF(N, F) LM_LDS_WAIT8(N, F[0], F[1], F[2], F[3], F[4], F[5], F[6], F[7])
-#define H3P_STEP(FC, FN, NDY, NDX) \
-    do {                           \
-        H3P_READS(FN, NDY, NDX);   \
-        H3P_WAITF(8, FC);          \
-        H3P_MFMAS(FC);             \
+// one pipeline step: issue the reads of the NEXT tap into FN, wait for the current set FC, run its MFMAs
+#define H3P_STEP(FC, FN, AS, NDY, NDX) \
+    do {                               \
+        H3P_READS(FN, AS, NDY, NDX);   \
+        H3P_WAITF(8, FC);              \
+        H3P_MFMAS(FC);                 \
     } while (0)
-#ifndef LM_H3P_PIPE
-#define LM_H3P_PIPE 1
-#endif
+#define H3P_STEP_D(FC, FN, AS, NDY, NDX, K0) \
+    do {                                     \
+        H3P_READS(FN, AS, NDY, NDX);         \
+        H3P_WAITF(8, FC);                    \
+        H3P_MFMAS_D(FC, K0);                 \
+    } while (0)
+// taps 0..7 of the chunk in buffer AS (tap 0 already in flight in FA); leaves tap 8 in flight in FA
+#define H3P_CHUNK_STEPS(FA, FB, AS)          \
+    do {                                     \
+        H3P_STEP_D(FA, FB, AS, 0, 1, 0);     \
+        H3P_STEP_D(FB, FA, AS, 0, 2, 4);     \
+        H3P_STEP_D(FA, FB, AS, 1, 0, 8);     \
+        H3P_STEP(FB, FA, AS, 1, 1);          \
+        H3P_STEP(FA, FB, AS, 1, 2);          \
+        H3P_STEP(FB, FA, AS, 2, 0);          \
+        H3P_STEP(FA, FB, AS, 2, 1);          \
+        H3P_STEP(FB, FA, AS, 2, 2);          \
+    } while (0)
 
 template <int TAPS, bool G16>
 __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptiles, int n_items, int xcd_order) {
@@ -348,16 +375,19 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
             pyx[j] = py | (px << 8) | (sl << 16);
         }
     }
-    unsigned relW0;
+    unsigned voffW;  // weight row of this lane in piece `wave`; piece wave + 8 j lies two taps further per j
     {
         const int idx = wave * 64 + lane;
         const int row = idx >> 2, ls = (idx & 3) ^ ((row >> 2) & 3);
         const int tap = row / TN, n = row - tap * TN;
-        relW0 = (unsigned)((tap * p.Cout + n) * p.Cin * 4 + (ls >> 1) * 32 + (ls & 1) * 16);
+        voffW = (unsigned)((tap * p.Cout + n) * p.Cin * 4 + (ls >> 1) * 32 + (ls & 1) * 16);
     }
     const unsigned w_piece_stride = (unsigned)(NW * 64 / 4 / TN) * (unsigned)p.Cout * (unsigned)p.Cin * 4u;
+    const unsigned slice_bytes = (unsigned)p.H * (unsigned)p.W * (unsigned)p.in_cstride * 4u;
+    const lm_rsrc rsrcA = lm_make_rsrc(p.in + (size_t)p.in_coff * 4, (size_t)p.B * slice_bytes - (size_t)p.in_coff * 4);
+    const lm_rsrc rsrcW = lm_make_rsrc(p.w, (size_t)TAPS * p.Cout * p.Cin * 4);
     const int tiles_x = p.W / TWW;
-    const int nchunks = p.Cin / KC;
+    const int nchunks = p.Cin / KC;  // even (checked by the launcher)
     const bool bn = p.bn_s != nullptr;
 
     // Work-item order.  `it` runs over a (padded) index space; workgroup g takes it = g, g + grid, ... and lives on XCD
@@ -389,38 +419,49 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
         n0 = ct * TN;
         return valid;
     };
-
-    // Stage chunk c0 of item (b,y0,x0,n0) into buffer `par`.  Compiler-visible LDS stores (zero fill of the
-    // out-of-image halo slots, epilogue constants) come FIRST, while no LDS-DMA is in flight; then the DMAs.
-    auto issue = [&](int b, int y0, int x0, int n0, int c0, int par, bool first_of_item, int epar) {
-        char* buf = lds + par * SM::BUF_BYTES;
-        bool inb[SM::A_PER_WAVE];
+    // per-lane source offsets of the halo tile of item (b, y0, x0), relative to slice b of rsrcA
+    auto item_voffs = [&](int b, int y0, int x0, unsigned* voff) __attribute__((always_inline)) {
+        const int ioff = ((y0 - HALO) * p.W + (x0 - HALO)) * p.in_cstride * 4;  // may be negative; the sum below is not
 #pragma unroll
         for (int j = 0; j < SM::A_PER_WAVE; ++j) {
             const int gy = y0 + (pyx[j] & 0xff) - HALO, gx = x0 + ((pyx[j] >> 8) & 0xff) - HALO;
-            inb[j] = pyx[j] >= 0 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && b + (pyx[j] >> 16) < p.B;
-            if (pyx[j] >= 0 && !inb[j]) {
-                const uint4 z = {0u, 0u, 0u, 0u};
-                *reinterpret_cast<uint4*>(buf + ((wave + NW * j) * 64 + lane) * 16) = z;
-            }
+            const bool inb = pyx[j] >= 0 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && b + (pyx[j] >> 16) < p.B;
+            voff[j] = inb ? (unsigned)((int)relA[j] + ioff) : LM_DMA_OOB;
         }
-        const unsigned cb = (unsigned)c0 * 4u;
-        if (first_of_item && wave < (bn ? 3 : 1)) {  // epilogue constants of the item: 64 floats per array = one 4-byte DMA per wave
-            const float* src = wave == 0 ? p.bias : (wave == 1 ? p.bn_s : p.bn_t);
-            lm_global_load_lds4(src + n0 + lane, &epi[epar][wave][0]);
-        }
-        // base of the halo tile's top-left pixel; may lie before the tensor for border tiles, only in-image lanes use it
-        const char* in_base = p.in + ((long long)b * p.H * p.W * p.in_cstride + p.in_coff) * 4 +
-                              ((long long)(y0 - HALO) * p.W + (x0 - HALO)) * (long long)p.in_cstride * 4;
+    };
+
+    // ---- the pending stage: the chunk whose DMA pieces the slots of the running taps issue
+    unsigned d_voff[SM::A_PER_WAVE];
+    unsigned d_soffA = 0, d_soffW = 0;
+    char* d_buf = lds;
+    int d_nA = 0, d_nW = 0, d_epi = -1, d_n0 = 0;  // piece counts (0: nothing to stage); epi buffer to fill or -1
+    auto set_dma = [&](const unsigned* voff, int b, int n0, int c0, int par, bool on, int epar_or_neg) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < SM::A_PER_WAVE; ++j) {
-            if (inb[j]) lm_global_load_lds16(in_base + (size_t)(relA[j] + cb), buf + (wave + NW * j) * 1024);
-        }
-        const char* w_base = p.w + (size_t)n0 * p.Cin * 4;
-#pragma unroll
-        for (int j = 0; j < SM::W_PER_WAVE; ++j) {
-            if (wave + NW * j < SM::W_PIECES)  // wave-uniform
-                lm_global_load_lds16(w_base + (size_t)(relW0 + (unsigned)j * w_piece_stride + cb), buf + SM::A_BYTES + (wave + NW * j) * 1024);
+        for (int j = 0; j < SM::A_PER_WAVE; ++j) d_voff[j] = voff[j];
+        d_soffA = (unsigned)b * slice_bytes + (unsigned)c0 * 4u;
+        d_soffW = ((unsigned)n0 * (unsigned)p.Cin + (unsigned)c0) * 4u;
+        d_buf = lds + par * SM::BUF_BYTES;
+        on = on && !LM_ABL_DMA(c0);
+        d_nA = on ? SM::A_PIECES : 0;
+        d_nW = on ? SM::W_PIECES : 0;
+        d_epi = on ? epar_or_neg : -1;
+        d_n0 = n0;
+    };
+    // slot k of the stage: k = 2 j -> activation piece wave + 8 j, k = 2 j + 1 -> weight piece wave + 8 j, the last slot
+    // -> the item's epilogue constants (64 floats per array = one 4-byte DMA per wave).  Every condition is wave-uniform.
+    constexpr int N_SLOTS = 12;
+    // this lane's element of the constant array its wave stages (a per-lane pointer: no kernel-argument reload in the tap loop)
+    const float* const epi_src = (wave == 0 ? p.bias : (wave == 1 ? p.bn_s : p.bn_t)) + lane;
+    static_assert(2 * SM::A_PER_WAVE <= N_SLOTS && 2 * SM::W_PER_WAVE + 1 <= N_SLOTS, "DMA slots");
+    auto dma_slot = [&](int k) __attribute__((always_inline)) {
+        const int j = k >> 1;
+        if (k == N_SLOTS - 1) {
+            if (d_epi >= 0 && wave < (bn ? 3 : 1)) lm_dma4_global(epi_src + d_n0, &epi[d_epi][wave][0]);
+        } else if ((k & 1) == 0) {
+            if (j < SM::A_PER_WAVE && wave + NW * j < d_nA) lm_dma16(rsrcA, d_voff[j < SM::A_PER_WAVE ? j : 0], d_soffA, d_buf + (wave + NW * j) * 1024);
+        } else {
+            if (j < SM::W_PER_WAVE && wave + NW * j < d_nW)
+                lm_dma16(rsrcW, voffW, d_soffW + (unsigned)j * w_piece_stride, d_buf + SM::A_BYTES + (wave + NW * j) * 1024);
         }
     };
 
@@ -438,8 +479,17 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
         for (int i = tid; i < p.head_C * 64; i += 512) hw[i] = p.head_w[i];
         if (tid < p.head_C) hw[kMaxClasses * 64 + tid] = p.head_b[tid];
     }
-    int par = 0, epar = 0;
-    issue(b, y0, x0, n0, 0, par, true, epar);
+    unsigned voffC[SM::A_PER_WAVE], voffN[SM::A_PER_WAVE];  // this item's / the next item's source offsets
+    item_voffs(b, y0, x0, voffC);
+    int epar = 0;
+    char* const buf0 = lds;
+    char* const buf1 = lds + SM::BUF_BYTES;
+    // prologue: chunk 0 of the first item, all pieces at once
+    set_dma(voffC, b, n0, 0, 0, true, epar);
+#pragma unroll
+    for (int k = 0; k < N_SLOTS; ++k) dma_slot(k);
+    lm_barrier_dma();
+    LM_TRACE_INIT();
     while (true) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -453,37 +503,60 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
         int nb = 0, ny0 = 0, nx0 = 0, nn0 = 0;
         while (nit < n_items && !decode(nit, nb, ny0, nx0, nn0)) nit += gridDim.x;
         const bool have_next = nit < n_items;
-        for (int ci = 0; ci < nchunks; ++ci) {
-            lm_dma_wait_all();
-            __syncthreads();  // chunk ci of this item has landed in buffer `par`; everyone is done with the other buffer
-            if (ci + 1 < nchunks) issue(b, y0, x0, n0, (ci + 1) * KC, par ^ 1, false, epar);
-            else if (have_next) issue(nb, ny0, nx0, nn0, 0, par ^ 1, true, epar ^ 1);
-            const char* as = lds + par * SM::BUF_BYTES;
-            lm_h16x8 f[8];  // whi0 whi1 wlo0 wlo1 a0hi a0lo a1hi a1lo
-            if (TAPS == 9 && LM_H3P_PIPE) {
-                lm_h16x8 g[8];
-                H3P_READS(f, 0, 0);
-                H3P_STEP(f, g, 0, 1); H3P_STEP(g, f, 0, 2); H3P_STEP(f, g, 1, 0); H3P_STEP(g, f, 1, 1);
-                H3P_STEP(f, g, 1, 2); H3P_STEP(g, f, 2, 0); H3P_STEP(f, g, 2, 1); H3P_STEP(g, f, 2, 2);
+        item_voffs(nb, ny0, nx0, voffN);
+        // chunk 0 of this item is resident in buffer 0 (and visible: a barrier lies behind its DMA wait)
+        lm_h16x8 f[8], g[8];  // two fragment sets: whi0 whi1 wlo0 wlo1 a0hi a0lo a1hi a1lo
+        bool abl_r = false;   // lab ablation (constant false in the product)
+        if constexpr (TAPS == 9) {
+            set_dma(voffC, b, n0, KC, 1, true, -1);  // chunk 1 -> buffer 1, issued from the slots of chunk 0
+            H3P_READS(f, buf0, 0, 0);
+            for (int ci = 0; ci < nchunks; ci += 2) {
+                abl_r = LM_ABL_READS(ci);
+                // ---- even chunk ci (buffer 0), fragments start in f
+                H3P_CHUNK_STEPS(f, g, buf0);
+                H3P_WAITF(0, f);
+                LM_TRACE_MARK(0);
+                lm_barrier_dma();  // everyone has read buffer 0 for the last time; chunk ci + 1 is complete in buffer 1
+                LM_TRACE_MARK(1);
+                H3P_READS(g, buf1, 0, 0);
+                if (ci + 2 < nchunks) set_dma(voffC, b, n0, (ci + 2) * KC, 0, true, -1);
+                else set_dma(voffN, nb, nn0, 0, 0, have_next, epar ^ 1);  // the next item's chunk 0 + epilogue constants
+                H3P_MFMAS(f);
+                // ---- odd chunk ci + 1 (buffer 1), fragments start in g
+                H3P_CHUNK_STEPS(g, f, buf1);
+                H3P_WAITF(0, g);
+                LM_TRACE_MARK(0);
+                lm_barrier_dma();
+                LM_TRACE_MARK(1);
+                if (ci + 2 < nchunks) {
+                    H3P_READS(f, buf0, 0, 0);
+                    set_dma(voffC, b, n0, (ci + 3) * KC, 1, true, -1);
+                } else {
+                    set_dma(voffC, b, n0, 0, 1, false, -1);  // buffer 1 becomes the epilogue's staging area
+                }
+                H3P_MFMAS(g);
+            }
+        } else {
+            for (int ci = 0; ci < nchunks; ++ci) {
+                // chunk ci is resident in buffer ci & 1; stage the next one (or the next item's first) into the other
+                const char* as = (ci & 1) ? buf1 : buf0;
+                if (ci + 1 < nchunks) set_dma(voffC, b, n0, (ci + 1) * KC, (ci + 1) & 1, true, -1);
+                else set_dma(voffN, nb, nn0, 0, 0, have_next, epar ^ 1);
+#pragma unroll
+                for (int k = 0; k < N_SLOTS; ++k) dma_slot(k);
+                H3P_READS(f, as, 0, 0);
                 H3P_WAITF(0, f);
                 H3P_MFMAS(f);
-            } else if (TAPS == 9) {
-                H3P_TAP(0, 0); H3P_TAP(0, 1); H3P_TAP(0, 2);
-                H3P_TAP(1, 0); H3P_TAP(1, 1); H3P_TAP(1, 2);
-                H3P_TAP(2, 0); H3P_TAP(2, 1); H3P_TAP(2, 2);
-            } else {
-                H3P_TAP(0, 0);
+                lm_barrier_dma();
             }
-            par ^= 1;
         }
-        // ---- epilogue of this item (the first chunk of the next item is already in flight)
+        LM_TRACE_MARK(2);
+        // ---- epilogue of this item (the first chunk of the next item is already resident in buffer 0)
         {
-            // All waves are done with the buffer of the last chunk: it becomes the staging area that turns the
+            // All waves are done with the buffer of the last chunk (buffer 1): it becomes the staging area that turns the
             // accumulator layout (lane = pixel, 8 bytes per 4 couts: 64 scattered lines per store) into full
             // 256-byte pixel rows written 16 bytes per lane (the scattered form cost ~10 us per tile in the TA).
-            lm_dma_wait_all();
-            __syncthreads();
-            char* stage = (STAGE_EXTRA ? lds + 2 * SM::BUF_BYTES : lds + (par ^ 1) * SM::BUF_BYTES) + wave * (32 * PSTR);
+            char* stage = (STAGE_EXTRA ? lds + 2 * SM::BUF_BYTES : buf1) + wave * (32 * PSTR);
             const int bs = b + wsl;                      // slice this wave writes
             const int yb = y0 + (G16 ? 4 * (wave & 3) : 2 * wave);  // first image row of the wave's N-tile 0
             const int Hp = p.H >> 1, Wp = p.W >> 1;
@@ -501,8 +574,8 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                     float vv[8][4];
 #pragma unroll
                     for (int mg = 0; mg < 8; ++mg) {
-                        const int mt = mg >> 2, g = mg & 3;
-                        const int cl = 32 * mt + 8 * g + 4 * kb;
+                        const int mt = mg >> 2, g4 = mg & 3;
+                        const int cl = 32 * mt + 8 * g4 + 4 * kb;
                         lm_h16x8 e0, e1, e2;
                         LM_LDS_READ128(e0, ep + cl * 4, 0);
                         LM_LDS_READ128(e1, ep + cl * 4, TN * 4);
@@ -513,7 +586,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                         float v[4];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            float t = fmaf(accm[mt][nt][4 * g + k], p.acc_scale, bb[k]);
+                            float t = fmaf(accm[mt][nt][4 * g4 + k], p.acc_scale, bb[k]);
                             if (bn) t = fmaf(fmaxf(t, 0.f), ss[k], tt[k]);
                             v[k] = t;
                         }
@@ -558,8 +631,8 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                 const bool tile_ok = bs < p.B && (G16 ? yb + 2 * nt + 1 < p.H : yb + nt < p.H);
 #pragma unroll
                 for (int mg = 0; mg < 8; ++mg) {
-                    const int mt = mg >> 2, g = mg & 3;
-                    const int cl = 32 * mt + 8 * g + 4 * kb;  // first of 4 consecutive local output channels
+                    const int mt = mg >> 2, g4 = mg & 3;
+                    const int cl = 32 * mt + 8 * g4 + 4 * kb;  // first of 4 consecutive local output channels
                     lm_h16x8 e0, e1, e2;
                     LM_LDS_READ128(e0, ep + cl * 4, 0);
                     LM_LDS_READ128(e1, ep + cl * 4, TN * 4);
@@ -570,7 +643,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                     float v[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        float t = fmaf(accm[mt][nt][4 * g + k], p.acc_scale, bb[k]);
+                        float t = fmaf(accm[mt][nt][4 * g4 + k], p.acc_scale, bb[k]);
                         if (bn) t = fmaf(fmaxf(t, 0.f), ss[k], tt[k]);
                         v[k] = t;
                         if (!G16) pl[mg][k] = nt == 0 ? t : pl[mg][k] + t;
@@ -622,31 +695,43 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
             }
             }  // stored-output epilogue
         }
+        LM_TRACE_MARK(3);
         if (!have_next) break;
         it = nit;
         b = nb;
         y0 = ny0;
         x0 = nx0;
         n0 = nn0;
+#pragma unroll
+        for (int j = 0; j < SM::A_PER_WAVE; ++j) voffC[j] = voffN[j];
         epar ^= 1;
+        // the staging area (buffer 1 for the 3x3 form) is rewritten by the DMA of the new item's chunk 1: every wave must have
+        // finished its staging reads.  No DMA is outstanding here, so the global stores of the epilogue need not be waited for.
+        lm_barrier_lds();
+        LM_TRACE_MARK(4);
     }
+    LM_TRACE_FLUSH();
+}
+
+// The persistent kernel addresses a tensor through a raw buffer descriptor with 32-bit offsets whose top bit marks an
+// out-of-image lane: it serves tensors below 2 GiB with an even number of 16-channel chunks (every level of the network;
+// batches are cut into sub-batches that fit); anything else takes the simple kernel.
+static bool h3_persistent_ok(const ConvParamsH3& p, int taps) {
+    // LM_H3_FALLBACK=1 forces the simple 4-wave kernel everywhere (it normally only serves odd widths): test hook
+    static const bool wide_ok = [] { const char* e = getenv("LM_H3_FALLBACK"); return !(e && e[0] == '1'); }();
+    const size_t slice_bytes = (size_t)p.H * p.W * p.in_cstride * 4;
+    return wide_ok && (p.W % 32 == 0 || p.W == 16) && (p.Cin / KC) % 2 == 0 && 2 * slice_bytes < 0x7fffffffull &&
+           (size_t)taps * p.Cout * p.Cin * 4 < 0x7fffffffull;
 }
 
 template <int TAPS>
 static hipError_t launch_conv_h3_t(const ConvParamsH3& p, hipStream_t stream) {
     if (p.Cin % KC != 0 || p.Cout % TN != 0 || (p.in_cstride & 7) || (p.in_coff & 7) || (p.out_cstride & 7) || (p.out_coff & 7)) return hipErrorInvalidValue;
     if (p.pool != nullptr && (((p.H | p.W) & 1) || (p.pool_cstride & 7) || (p.pool_coff & 7))) return hipErrorInvalidValue;
-    const ConvParamsH3& pd = p;
-    // LM_H3_FALLBACK=1 forces the simple 4-wave kernel everywhere (it normally only serves odd widths): test hook
-    static const bool wide_ok = [] { const char* e = getenv("LM_H3_FALLBACK"); return !(e && e[0] == '1'); }();
-    const bool g16 = p.W == 16;
-    if (wide_ok && (p.W % 32 == 0 || g16) && (size_t)2 * p.H * p.W * p.in_cstride * 4 < 0x7fffffffull && (size_t)TAPS * p.Cout * p.Cin * 4 < 0x7fffffffull) {
-        const int n_ptiles = g16 ? ((p.H + TH - 1) / TH) * ((p.B + 1) / 2) : (p.W / 32) * ((p.H + TH - 1) / TH) * p.B;
-        // LM_H3_ORDER: 0 cout-major everywhere, 1 XCD-aware pixel-tile-major everywhere, default: per layer (see below)
+    if (h3_persistent_ok(p, TAPS)) {
+        const bool g16 = p.W == 16;
+        // LM_H3_ORDER: 0 cout-major everywhere, 1 XCD-aware pixel-tile-major everywhere, default: per layer (see the kernel)
         static const int order_env = [] { const char* e = getenv("LM_H3_ORDER"); return e ? atoi(e) : -1; }();
-        const int n_ct = p.Cout / TN;
-        const int xcd_order = order_env >= 0 ? order_env : (n_ct >= 2 && n_ptiles >= 64 ? 1 : 0);
-        const int n_items = xcd_order ? 8 * ((n_ptiles + 7) / 8) * n_ct : n_ptiles * n_ct;
         static const int n_cu = [] {
 #ifdef LM_EMU_BUILD
             return 4;
@@ -656,23 +741,34 @@ static hipError_t launch_conv_h3_t(const ConvParamsH3& p, hipStream_t stream) {
             return n > 0 ? n : 256;
 #endif
         }();
-        const unsigned blocks = (unsigned)std::min(n_items, n_cu);
-        if (g16)
-            LM_LAUNCH((conv_igemm_h3p<TAPS, true>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
-        else
-            LM_LAUNCH((conv_igemm_h3p<TAPS, false>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
-        return hipGetLastError();
+        // sub-batches whose input tensor stays below 2 GiB (an even number of slices: the 16-wide geometry pairs them)
+        const size_t slice_bytes = (size_t)p.H * p.W * p.in_cstride * 4;
+        const int max_b = std::max(2, (int)(0x7fffffffull / slice_bytes) & ~1);
+        for (int b0 = 0; b0 < p.B; b0 += max_b) {
+            ConvParamsH3 pd = p;
+            pd.B = std::min(max_b, p.B - b0);
+            pd.in = p.in + (size_t)b0 * slice_bytes;
+            pd.out = p.out + (size_t)b0 * p.H * p.W * p.out_cstride * 4;
+            if (p.pool) pd.pool = p.pool + (size_t)b0 * (p.H / 2) * (p.W / 2) * p.pool_cstride * 4;
+            if (p.head_labels) pd.head_labels = p.head_labels + (size_t)b0 * p.H * p.W;
+            const int n_ptiles = g16 ? ((p.H + TH - 1) / TH) * ((pd.B + 1) / 2) : (p.W / 32) * ((p.H + TH - 1) / TH) * pd.B;
+            const int n_ct = p.Cout / TN;
+            const int xcd_order = order_env >= 0 ? order_env : (n_ct >= 2 && n_ptiles >= 64 ? 1 : 0);
+            const int n_items = xcd_order ? 8 * ((n_ptiles + 7) / 8) * n_ct : n_ptiles * n_ct;
+            const unsigned blocks = (unsigned)std::min(n_items, n_cu);
+            if (g16)
+                LM_LAUNCH((conv_igemm_h3p<TAPS, true>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
+            else
+                LM_LAUNCH((conv_igemm_h3p<TAPS, false>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
+            const hipError_t err = hipGetLastError();
+            if (err != hipSuccess) return err;
+        }
+        return hipSuccess;
     }
     const int tiles = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH);
     dim3 grid((unsigned)(tiles * p.B), (unsigned)(p.Cout / TN));
     LM_LAUNCH((conv_igemm_h3<TAPS>), grid, dim3(256), (H3Smem<TAPS>::BYTES), stream, p);
     return hipGetLastError();
-}
-
-static bool h3_persistent_ok(const ConvParamsH3& p, int taps) {
-    static const bool wide_ok = [] { const char* e = getenv("LM_H3_FALLBACK"); return !(e && e[0] == '1'); }();
-    return wide_ok && (p.W % 32 == 0 || p.W == 16) && (size_t)2 * p.H * p.W * p.in_cstride * 4 < 0x7fffffffull &&
-           (size_t)taps * p.Cout * p.Cin * 4 < 0x7fffffffull;
 }
 
 bool conv3x3_h3_can_fuse_head(const ConvParamsH3& p) {

@@ -8,3 +8,4 @@ if not logger.handlers:
     _h = logging.StreamHandler(sys.stdout)
     _h.setFormatter(logging.Formatter("lungmask %(asctime)s %(message)s", datefmt="%Y-%m-%d %H:%M:%S"))
     logger.addHandler(_h)
+    logger.propagate = False  # lungmask/logger.py:6

@@ -167,8 +167,28 @@ def make_prepost():
     print("prepost golden:", len(out), "arrays")
 
 
+def make_testvol():
+    """The reference's end-to-end fixture volume (tests/test_mask.py:12-14: read_dicoms(tests/testdata)[0], two 512x512 CT
+    slices) as a small .npz, so that the golden voxel-count tests of tests/test_mask.py:36,47,59 can run on a GPU box
+    (which has no /root/reference) as soon as the pretrained weights are provided.  pydicom / SimpleITK are absent here, so
+    the slices are read by lungmask_amd.volume_io (the same series logic, utils.py:132-230); the raw pixel block of each file
+    (int16 at byte offset 910, tests/test_utils.py:18-55 wrote them) is checked against what the reader returns."""
+    from lungmask_amd import volume_io
+
+    td = "/root/reference/tests/testdata"
+    vol = volume_io.read_dicoms(td)[0]
+    raws = [np.frombuffer(open(os.path.join(td, f), "rb").read()[910 : 910 + 512 * 512 * 2], dtype="<i2").reshape(512, 512) for f in ("0.dcm", "1.dcm")]
+    assert vol.array.shape == (2, 512, 512)
+    assert all(any(np.array_equal(vol.array[i], r) for r in raws) for i in range(2))  # rescale slope 1 / intercept 0
+    np.savez_compressed(os.path.join(GOLD, "testvol.npz"), vol=vol.array, direction=np.asarray(vol.direction, dtype=np.float64),
+                        spacing=np.asarray(vol.spacing, dtype=np.float64))
+    print("testvol golden:", vol.array.shape, vol.array.dtype)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["unet", "prepost"]
+    which = sys.argv[1:] or ["unet", "prepost", "testvol"]
+    if "testvol" in which:
+        make_testvol()
     if "prepost" in which:
         make_prepost()
     if "unet" in which:

@@ -14,6 +14,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: long-running CPU emulation test")
 
 
+def pytest_collection_modifyitems(config, items):
+    """`-m gpu` tests need a device: on a box without one (no /dev/kfd) they are skipped instead of erroring in
+    lm_engine_create, so that a plain `pytest tests` works everywhere.  LM_REQUIRE_GPU=1 (set it on a GPU box) turns the
+    skip back into a hard failure -- there is no CPU fallback to hide behind."""
+    if os.path.exists("/dev/kfd") or os.environ.get("LM_REQUIRE_GPU") == "1":
+        return
+    skip = pytest.mark.skip(reason="no AMD GPU on this machine (/dev/kfd missing)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLD

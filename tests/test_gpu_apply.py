@@ -120,12 +120,59 @@ def test_lminferer_dropin_api(gpu_engine, tmp_path):
     assert np.array_equal(res, gpu_engine.apply(0, vol))
 
 
-def test_real_weights_golden_counts_if_available(gpu_engine):
-    """tests/test_mask.py:30-36 golden voxel counts -- needs the pretrained .pth (no network here)."""
+def _weights_dir_with(*names):
     wd = os.environ.get("LUNGMASK_WEIGHTS_DIR")
-    if not wd or not os.path.exists(os.path.join(wd, "unet_r231-d5d2fc3d.pth")):
-        pytest.skip("pretrained weights not available offline")
-    pytest.skip("fixture DICOM not shipped; see INTEGRATION.md")
+    if not wd or not all(os.path.exists(os.path.join(wd, n)) for n in names):
+        pytest.skip("pretrained weights not available offline: set LUNGMASK_WEIGHTS_DIR to a folder holding " + ", ".join(names))
+    return wd
+
+
+@pytest.fixture(scope="module")
+def reference_testvol(golden_dir):
+    """read_dicoms(tests/testdata)[0] of the reference (tests/test_mask.py:12-14), committed by oracle/make_golden.py testvol"""
+    return np.load(os.path.join(golden_dir, "testvol.npz"))["vol"]
+
+
+def test_real_weights_golden_counts_r231(gpu_engine, reference_testvol):
+    """The reference's own end-to-end known answers (tests/test_mask.py:30-47), written as the reference writes them --
+    force_cpu=True included -- against the pretrained R231 weights.  Opt-in: runs when $LUNGMASK_WEIGHTS_DIR holds the .pth."""
+    from lungmask_amd import LMInferer
+
+    wd = _weights_dir_with("unet_r231-d5d2fc3d.pth")
+    inferer = LMInferer(force_cpu=True, tqdm_disable=True)
+    res = inferer.apply(reference_testvol)
+    assert np.all(np.unique(res, return_counts=True)[1] == [423000, 64752, 36536])
+    # a path to the R231 weights with LTRCLobes as model name: the name is ignored, 3 classes come out (test_mask.py:38-47)
+    inferer = LMInferer(modelname="LTRCLobes", modelpath=os.path.join(wd, "unet_r231-d5d2fc3d.pth"), force_cpu=True, tqdm_disable=True)
+    res = inferer.apply(reference_testvol)
+    assert np.all(np.unique(res, return_counts=True)[1] == [423000, 64752, 36536])
+
+
+def test_real_weights_golden_counts_fused(gpu_engine, reference_testvol):
+    """tests/test_mask.py:50-61: LTRCLobes filled by R231."""
+    from lungmask_amd import LMInferer
+
+    _weights_dir_with("unet_r231-d5d2fc3d.pth", "unet_ltrclobes-3a07043d.pth")
+    inferer = LMInferer(modelname="LTRCLobes", force_cpu=True, fillmodel="R231", tqdm_disable=True)
+    res = inferer.apply(reference_testvol)
+    assert np.all(np.unique(res, return_counts=True)[1] == [423000, 13334, 23202, 23834, 40918])
+
+
+def test_force_cpu_is_accepted(gpu_engine, tmp_path, monkeypatch):
+    """force_cpu=True (every end-to-end test of the reference passes it) is accepted and logged, the engine still runs on the
+    GPU; LUNGMASK_AMD_STRICT_CPU=1 makes it an error."""
+    from lungmask_amd import LMInferer
+
+    p = tmp_path / "unet_synth.pth"
+    sd = uo.synthetic_state_dict(3)
+    torch.save(sd, p)
+    vol = po.phantom(2, 512, 512, seed=5)
+    a = LMInferer(modelpath=str(p), force_cpu=True, tqdm_disable=True).apply(vol)
+    b = LMInferer(modelpath=str(p), tqdm_disable=True).apply(vol)
+    assert np.array_equal(a, b)
+    monkeypatch.setenv("LUNGMASK_AMD_STRICT_CPU", "1")
+    with pytest.raises(RuntimeError):
+        LMInferer(modelpath=str(p), force_cpu=True)
 
 
 def test_sharded_pipeline_world1_on_torch_cuda_tensors(gpu_engine):

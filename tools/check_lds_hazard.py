@@ -132,25 +132,31 @@ for km in re.finditer(r"^(_ZN2lm14conv_igemm_h3pI[^:\n]*):[^\n]*\n(.*?)^\s*s_end
                     work.append((nx, tuple(frozenset(x) for x in out)))
     checked += sum(1 for lab in order for l in blocks[lab] if l.startswith("@ds_read_b128"))
 
-# Second invariant: every workgroup barrier of these kernels publishes LDS-DMA data, so each wave must have drained its own
-# DMAs (s_waitcnt vmcnt(0)) after its last global_load_lds and before the s_barrier (hipcc once dropped that wait on one path).
-barriers = 0
+# Second invariant: a workgroup barrier of these kernels either publishes LDS-DMA data -- then each wave must have drained its
+# own DMAs (s_waitcnt vmcnt(0)) after its last DMA and before the s_barrier (hipcc once dropped that wait on one path; the
+# hand-written lm_barrier_dma() carries it in the same asm statement) -- or it is the item-switch barrier that only orders LDS
+# accesses (lm_barrier_lds(), tagged LM_BARRIER_LDS_ONLY in the asm text): that one needs lgkmcnt(0) in front.
+barriers = lds_only = 0
 for km in re.finditer(r"^(_ZN2lm14conv_igemm_h3pI[^:\n]*):[^\n]*\n(.*?)^\s*s_endpgm", asm, re.S | re.M):
-    name, lines = km.group(1), [l.split(";")[0].strip() for l in km.group(2).splitlines()]
+    name, raw_lines = km.group(1), km.group(2).splitlines()
+    lines = [l.split(";")[0].strip() for l in raw_lines]
     for i, ln in enumerate(lines):
         if ln != "s_barrier":
             continue
         barriers += 1
+        tagged = "LM_BARRIER_LDS_ONLY" in raw_lines[i]
+        lds_only += tagged
+        want = "lgkmcnt(0)" if tagged else "vmcnt(0)"
         ok = False
         for j in range(i - 1, max(i - 40, -1), -1):
-            if "global_load_lds" in lines[j] or lines[j].endswith(":") and not lines[j].startswith("."):
+            if "global_load_lds" in lines[j] or (lines[j].startswith("buffer_load") and lines[j].endswith("lds")) or lines[j].endswith(":") and not lines[j].startswith("."):
                 break
-            if lines[j].startswith("s_waitcnt") and "vmcnt(0)" in lines[j]:
+            if lines[j].startswith("s_waitcnt") and want in lines[j]:
                 ok = True
                 break
         if not ok:
-            print(f"{name}: s_barrier without a preceding s_waitcnt vmcnt(0)")
+            print(f"{name}: s_barrier without a preceding s_waitcnt {want}")
             bad += 1
-print(f"{barriers} barriers checked for the vmcnt(0) in front of them")
+print(f"{barriers} barriers checked for the wait in front of them ({lds_only} of them LDS-only)")
 print(f"{checked} hand-issued ds_read_b128 checked (in-flight state propagated along the control-flow graph), {bad} hazards")
 sys.exit(1 if bad else 0)
