@@ -76,6 +76,12 @@ int lm_model_classes(lm_engine* e, int slot);
  * measured max |log-prob error| vs the reference <= 1.7e-4); 0 = exact fp32 matrix ops
  * (v_mfma_f32_32x32x2_f32, 16x lower peak). */
 int lm_set_precision(lm_engine* e, int mode);
+/* The arithmetic the NEXT forward of `slot` will use: 1 split-f16, 0 exact fp32.  The split form stores activations as
+ * f16 pairs; its kernels watch the range (|v| >= 2^15 or non-finite), and a model that ever trips the guard is re-run --
+ * in the same call -- and pinned to the exact-fp32 kernels (the reference computes in fp32, resunet.py:58-70, and has no
+ * such range limit).  lm_forward_dev / lm_forward_batches_dev / lm_apply_* therefore return only after the forward has
+ * finished. */
+int lm_model_precision(lm_engine* e, int slot);
 
 /* ---- network forward (mask.py:178-186: model(mbt) + torch.max(pred,1)[1]) ------ */
 /* x_dev: f32 [b][h][w] (h, w multiples of 16).  labels_dev: u8 [b][h][w] or NULL.

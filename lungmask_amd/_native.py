@@ -62,6 +62,7 @@ class Library:
         L.lm_copy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.lm_model_load.argtypes = [C.c_void_p, C.c_int, C.POINTER(_Tensor), C.c_int]
         L.lm_model_classes.argtypes = [C.c_void_p, C.c_int]
+        L.lm_model_precision.argtypes = [C.c_void_p, C.c_int]
         L.lm_forward_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.lm_set_precision.argtypes = [C.c_void_p, C.c_int]
         L.lm_set_streams.argtypes = [C.c_void_p, C.c_int]
@@ -194,6 +195,11 @@ class Engine:
 
     def n_classes(self, slot: int) -> int:
         return self.L.check(self.L.lib.lm_model_classes(self.h, slot), "lm_model_classes")
+
+    def model_precision(self, slot: int) -> str:
+        """'split_f16' or 'f32': what the next forward of `slot` runs on (a model whose activations left the f16 range is
+        pinned to 'f32' by the engine's range guard)."""
+        return "split_f16" if self.L.check(self.L.lib.lm_model_precision(self.h, slot), "lm_model_precision") == 1 else "f32"
 
     # -- network
     def set_precision(self, mode):

@@ -70,6 +70,7 @@ void lm_engine_destroy(lm_engine* e) {
     for (auto& m : e->models) m.release();
     if (e->stream2) (void)hipStreamSynchronize(e->stream2);
     if (e->zero_page) (void)hipFree(e->zero_page);
+    if (e->range_flag_host) (void)hipHostFree(e->range_flag_host);
     e->nn.release();
     e->nn2.release();
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
@@ -124,6 +125,11 @@ int lm_model_classes(lm_engine* e, int slot) {
     return e->models[slot].n_classes;
 }
 
+int lm_model_precision(lm_engine* e, int slot) {
+    if (!e || slot < 0 || slot >= 4 || !e->models[slot].loaded) return LM_ERR_NOMODEL;
+    return (e->precision == 1 && !e->models[slot].force_f32) ? 1 : 0;
+}
+
 int lm_set_precision(lm_engine* e, int mode) {
     if (!e || (mode != 0 && mode != 1)) {
         set_error("lm_set_precision: mode must be 0 (exact fp32) or 1 (split-f16)");
@@ -145,13 +151,13 @@ int lm_set_streams(lm_engine* e, int n) {
 int lm_forward_batches_dev(lm_engine* e, int slot, const float* x_dev, int n, int h, int w, int batch_size, uint8_t* labels_dev) {
     if (!e || !x_dev || !labels_dev || n < 0) return LM_ERR_INVALID;
     LM_DEVICE(e);
-    return forward_batches(e, slot, x_dev, n, h, w, batch_size, labels_dev);
+    return forward_guarded(e, slot, x_dev, n, h, w, batch_size <= 0 ? 20 : batch_size, labels_dev, nullptr);
 }
 
 int lm_forward_dev(lm_engine* e, int slot, const float* x_dev, int b, int h, int w, uint8_t* labels_dev, float* logp_dev) {
     if (!e || !x_dev) return LM_ERR_INVALID;
     LM_DEVICE(e);
-    return forward(e, slot, x_dev, b, h, w, labels_dev, logp_dev);
+    return forward_guarded(e, slot, x_dev, b, h, w, 0, labels_dev, logp_dev);
 }
 
 int lm_preprocess_dev(lm_engine* e, const void* vol_dev, int dtype, int n, int h, int w, int oh, int ow, int32_t* bbox_dev,

@@ -55,6 +55,9 @@ struct Model {
     ConvLayer upc[4][2];   // up_path.i.conv_block.block.{0,3}
     float *head_w = nullptr, *head_b = nullptr;
     std::vector<void*> allocs;
+    // The split-f16 path stores activations as f16 pairs: a model whose activations left the f16 range (detected by the
+    // kernels' range guard) is pinned to the exact-fp32 kernels from then on.
+    bool force_f32 = false;
     void release();
 };
 
@@ -158,6 +161,8 @@ struct lm_engine {
     lm::Profiler prof;
     int precision = 1;  // 1 (default): split-f16 3-product; 0: exact fp32 matrix ops (lm_set_precision)
     char* zero_page = nullptr;
+    unsigned* range_flag = nullptr;       // device word of the f16 range guard (ConvParamsH3::range_flag)
+    unsigned* range_flag_host = nullptr;  // pinned copy
 };
 
 namespace lm {
@@ -165,6 +170,9 @@ int model_load(lm_engine* e, int slot, const lm_tensor* tensors, int n);
 int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t* labels, float* logp, int lane = 0);
 // n slices in batches of `batch` (mask.py:173-187), batches alternating over the engine's forward lanes
 int forward_batches(lm_engine* e, int slot, const float* x, int n, int H, int W, int batch, uint8_t* labels);
+// The two above + the f16 range guard: waits for the forward, and when a split-f16 forward reported activations beyond the f16
+// range, pins the model to the exact-fp32 kernels and runs the forward again.  What the C ABI and lm_apply call.
+int forward_guarded(lm_engine* e, int slot, const float* x, int n, int H, int W, int batch, uint8_t* labels, float* logp);
 int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spare, int n_spare, int skip_below);
 struct BoundaryRec;
 void replay_merge(int R, const int* area, const uint8_t* lv, const BoundaryRec* recs, size_t nrecs, const std::vector<int>& spare, int skip_below,

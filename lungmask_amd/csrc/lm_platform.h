@@ -187,9 +187,24 @@ extern __device__ unsigned* lm_h3_trace_ptr;
     } while (0)
 #endif
 
+// The remainder halves keep only their LM_LO_BITS leading mantissa bits (10 = all of them).  v = hi + lo then holds to
+// 2^-(12 + LM_LO_BITS) relative instead of 2^-22; the 1e-3 parity bar of the log-probabilities needs ~2^-16.  Why throw bits
+// away: MI355X clocks to a power budget and the matrix pipes' power follows the operands' toggling bits -- two thirds of the
+// conv kernel's matrix instructions have a remainder operand (tools/ubench/mfma_power.hip prices it).  Rounding is to nearest
+// (ties away from zero) on the bit pattern: add half of the dropped range, clear the dropped bits; a remainder is at most
+// 2^-11 of the f16 range, so the add never reaches the sign bit and two halves can be handled in one 32-bit register.
+#ifndef LM_LO_BITS
+#define LM_LO_BITS 10
+#endif
+__host__ __device__ __forceinline__ unsigned lm_round_lo_pair(unsigned two_halves) {
+    if (LM_LO_BITS >= 10) return two_halves;
+    constexpr unsigned half_ulp = (1u << (9 - (LM_LO_BITS < 10 ? LM_LO_BITS : 9))), keep = 0xffffu & ~((1u << (10 - (LM_LO_BITS < 10 ? LM_LO_BITS : 9))) - 1u);
+    return (two_halves + (half_ulp | half_ulp << 16)) & (keep | keep << 16);
+}
+
 // fp32 x4 -> split-f16: hi = f16(v), lo = f16(v - hi) (UNSCALED: for |v| < 2^-3 the remainder is an f16 denormal, which
 // conversions and the matrix instructions honour -- tools/ubench/mfma_denorm.hip -- so v = hi + lo to 2^-25 absolute or
-// 2^-22 relative, whichever is larger), each packed as 4 halves (8 bytes).
+// 2^-22 relative, whichever is larger; less when LM_LO_BITS < 10), each packed as 4 halves (8 bytes).
 // The vector form makes hipcc emit v_cvt_pk_f16_f32 / v_pk_add_f32 (2 VALU per value).
 __device__ __forceinline__ void lm_split4(float v0, float v1, float v2, float v3, uint2* hi, uint2* lo) {
 #ifdef LM_EMU_BUILD
@@ -207,6 +222,16 @@ __device__ __forceinline__ void lm_split4(float v0, float v1, float v2, float v3
     __builtin_memcpy(hi, &h, 8);
     __builtin_memcpy(lo, &l, 8);
 #endif
+    lo->x = lm_round_lo_pair(lo->x);
+    lo->y = lm_round_lo_pair(lo->y);
+}
+// one value (the first conv writes single channels)
+__device__ __forceinline__ lm_h16 lm_round_lo1(lm_h16 l) {
+    unsigned short u;
+    memcpy(&u, &l, 2);
+    u = (unsigned short)lm_round_lo_pair(u);
+    memcpy(&l, &u, 2);
+    return l;
 }
 
 // the values a consumer of the split pair sees: v' = f32(hi) + f32(lo)

@@ -62,6 +62,7 @@ void Model::release() {
     for (void* a : allocs) (void)hipFree(a);
     allocs.clear();
     loaded = false;
+    force_f32 = false;
 }
 
 // ------------------------------------------------------------------------------ profiler
@@ -220,7 +221,7 @@ int load_conv(Model& md, const TensorMap& tm, const std::string& conv, const std
                 for (int i = 0; i < cin; ++i) {
                     const float v = w->data[((size_t)o * cin + i) * taps + t] * up;
                     const uint16_t hi = f32_to_f16(v);
-                    const uint16_t lo = f32_to_f16(v - f16_to_f32(hi));
+                    const uint16_t lo = (uint16_t)lm_round_lo_pair(f32_to_f16(v - f16_to_f32(hi)));  // same rule as the activations
                     const size_t g = (((size_t)t * cout + o) * cin + (size_t)(i & ~7)) * 2;  // half index of the group start
                     hp[g + (i & 7)] = hi;
                     hp[g + 8 + (i & 7)] = lo;
@@ -308,6 +309,7 @@ struct Fwd {
     hipStream_t st;
     int B;
     int kc3, kc1, kfirst, kup, khead;
+    bool h3;  // split-f16 kernels (else the exact-fp32 ones)
 
     bool head_fused = false;  // set by conv() when the head ran inside the last conv's epilogue
 
@@ -338,12 +340,12 @@ struct Fwd {
         int kind = L.taps == 9 ? kc3 : kc1;
         if (e->prof.on && e->prof.per_layer) {
             char nm[48];
-            snprintf(nm, sizeof nm, "%s%s/H%d_Ci%d_Co%d", L.taps == 9 ? "conv3x3_igemm_" : "conv1x1_igemm_", e->precision == 1 ? "h3" : "f32", H, L.cin, L.cout);
+            snprintf(nm, sizeof nm, "%s%s/H%d_Ci%d_Co%d", L.taps == 9 ? "conv3x3_igemm_" : "conv1x1_igemm_", h3 ? "h3" : "f32", H, L.cin, L.cout);
             kind = e->prof.kind_id(nm);
         }
         e->prof.begin(st, kind, flops, bytes);
         hipError_t err;
-        if (e->precision == 1) {
+        if (h3) {
             ConvParamsH3 q{};
             q.in = reinterpret_cast<const char*>(in);
             q.in_cstride = in_cs;
@@ -360,6 +362,7 @@ struct Fwd {
             q.pool_cstride = pool_cs;
             q.pool_coff = pool_co;
             q.zeros = e->zero_page;
+            q.range_flag = e->range_flag;
             q.B = B;
             q.H = H;
             q.W = W;
@@ -408,19 +411,24 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
         LM_TRY(ws.pool[i].reserve((px >> (2 * i + 2)) * (64u << i) * 4));
     }
     float *t1 = ws.t1.as<float>(), *t2 = ws.t2.as<float>(), *t3 = ws.t3.as<float>();
-    const bool h3 = e->precision == 1;
+    const bool h3 = e->precision == 1 && !md.force_f32;
     Fwd f{e, stream, B, e->prof.kind_id(h3 ? "conv3x3_igemm_h3" : "conv3x3_igemm_f32"), e->prof.kind_id(h3 ? "conv1x1_igemm_h3" : "conv1x1_igemm_f32"),
-          e->prof.kind_id("first_conv"), e->prof.kind_id("upsample2x"), e->prof.kind_id("head_argmax")};
+          e->prof.kind_id("first_conv"), e->prof.kind_id("upsample2x"), e->prof.kind_id("head_argmax"), h3};
     if (h3 && !e->zero_page) {
         void* zp = nullptr;
-        LM_HIP(hipMalloc(&zp, 256));
-        LM_HIP(hipMemset(zp, 0, 256));
+        LM_HIP(hipMalloc(&zp, 512));
+        LM_HIP(hipMemset(zp, 0, 512));
         e->zero_page = reinterpret_cast<char*>(zp);
+        e->range_flag = reinterpret_cast<unsigned*>(e->zero_page + 256);  // own cache line, zero = "in range"
+        void* hp = nullptr;
+        LM_HIP(hipHostMalloc(&hp, 64, 0));
+        e->range_flag_host = reinterpret_cast<unsigned*>(hp);
+        *e->range_flag_host = 0;
     }
 
     // ---- encoder (resunet.py:60-64)
     {
-        FirstConvParams p{x, md.first.w, md.first.bias, md.first.bn_s, md.first.bn_t, t1, 64, 0, B, H, W};
+        FirstConvParams p{x, md.first.w, md.first.bias, md.first.bn_s, md.first.bn_t, t1, 64, 0, B, H, W, h3 ? e->range_flag : nullptr};
         e->prof.begin(stream, f.kfirst, 2.0 * px * 64 * 9, 4.0 * px * 65);
         hipError_t err = h3 ? launch_first_conv_h3(p, stream) : launch_first_conv(p, stream);
         e->prof.end(stream);
@@ -495,6 +503,33 @@ int forward_batches(lm_engine* e, int slot, const float* x, int n, int H, int W,
     if (dual) {
         LM_HIP(hipEventRecord(e->ev_join, e->stream2));
         LM_HIP(hipStreamWaitEvent(e->stream, e->ev_join, 0));
+    }
+    return LM_OK;
+}
+
+// ------------------------------------------------------------------------------ f16 range guard
+int forward_guarded(lm_engine* e, int slot, const float* x, int n, int H, int W, int batch, uint8_t* labels, float* logp) {
+    if (slot < 0 || slot >= 4 || !e->models[slot].loaded) {
+        set_error("model slot %d is empty", slot);
+        return LM_ERR_NOMODEL;
+    }
+    Model& md = e->models[slot];
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const bool h3 = e->precision == 1 && !md.force_f32;
+        if (logp != nullptr || batch <= 0) LM_TRY(forward(e, slot, x, n, H, W, labels, logp));
+        else LM_TRY(forward_batches(e, slot, x, n, H, W, batch, labels));
+        if (!h3 || e->range_flag == nullptr) return LM_OK;
+        // the lanes have been joined into the main stream: one 4-byte read-back behind them
+        LM_HIP(hipMemcpyAsync(e->range_flag_host, e->range_flag, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
+        LM_HIP(hipStreamSynchronize(e->stream));
+        if (*e->range_flag_host == 0) return LM_OK;
+        LM_HIP(hipMemsetAsync(e->range_flag, 0, sizeof(unsigned), e->stream));
+        *e->range_flag_host = 0;
+        md.force_f32 = true;
+        fprintf(stderr,
+                "lungmask_hip: activations of model slot %d left the f16 range (|v| >= 2^15): its forward passes run on the exact-fp32 "
+                "matrix kernels from now on (about 4x slower, same results as the reference)\n",
+                slot);
     }
     return LM_OK;
 }

@@ -33,6 +33,7 @@ struct FirstConvParams {
     float* out;
     int out_cstride, out_coff;
     int B, H, W;
+    unsigned* range_flag = nullptr;  // split-f16 form only: see ConvParamsH3::range_flag
 };
 
 struct UpsampleParams {
@@ -73,7 +74,12 @@ struct ConvParamsH3 {
     const float* head_b = nullptr;   // [C]
     uint8_t* head_labels = nullptr;  // [B][H][W]
     int head_C = 0;
+    // f16 range guard: hi = f16(v) overflows beyond 65504 and nothing downstream would notice.  Every producer of a split
+    // tensor ORs 1 into this device word when a value it writes is not below kF16Guard in magnitude (or is not finite);
+    // the engine checks the word after the forward and re-runs the model on the exact-fp32 kernels (nn_engine.hip).
+    unsigned* range_flag = nullptr;
 };
+constexpr float kF16Guard = 32768.f;  // 2^15: a factor 2 below the largest finite half
 // whether launch_conv3x3_h3 can take the fused head for this shape (else run launch_head_h3 on the stored output)
 bool conv3x3_h3_can_fuse_head(const ConvParamsH3& p);
 hipError_t launch_conv3x3_h3(const ConvParamsH3& p, hipStream_t stream);

@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(ConvParamsH3 p) {
 
     // ---- epilogue.  D[cout][pixel]: lane = pixel (li) of the N-tile, register quad g = 4 consecutive couts.
     const bool bn = p.bn_s != nullptr;
+    float amax = 0.f;  // f16 range guard (ConvParamsH3::range_flag)
     const int Hp = p.H >> 1, Wp = p.W >> 1;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(ConvParamsH3 p) {
                     v[2] = fmaf(fmaxf(v[2], 0.f), s.z, sh.z);
                     v[3] = fmaf(fmaxf(v[3], 0.f), s.w, sh.w);
                 }
+                amax = fmaxf(fmaxf(amax, fabsf(v[0])), fmaxf(fmaxf(fabsf(v[1]), fabsf(v[2])), fabsf(v[3])));
                 const int grp = cb >> 3;  // 8-channel group index inside the output tensor slice
                 if (inside) split_store4(orow + (size_t)grp * 32, (cb & 7) * 2, v[0], v[1], v[2], v[3]);
                 if (p.pool != nullptr) {  // avg_pool2d(2): partners are lane^1 (x+1) and lane^16 (y+1)
@@ -192,6 +194,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(ConvParamsH3 p) {
             }
         }
     }
+    if (p.range_flag != nullptr && !(amax < kF16Guard)) atomicOr(p.range_flag, 1u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -557,6 +560,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
             // accumulator layout (lane = pixel, 8 bytes per 4 couts: 64 scattered lines per store) into full
             // 256-byte pixel rows written 16 bytes per lane (the scattered form cost ~10 us per tile in the TA).
             char* stage = (STAGE_EXTRA ? lds + 2 * SM::BUF_BYTES : buf1) + wave * (32 * PSTR);
+            float amax = 0.f;  // largest magnitude this lane hands to the split (f16 range guard)
             const int bs = b + wsl;                      // slice this wave writes
             const int yb = y0 + (G16 ? 4 * (wave & 3) : 2 * wave);  // first image row of the wave's N-tile 0
             const int Hp = p.H >> 1, Wp = p.W >> 1;
@@ -589,6 +593,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                             float t = fmaf(accm[mt][nt][4 * g4 + k], p.acc_scale, bb[k]);
                             if (bn) t = fmaf(fmaxf(t, 0.f), ss[k], tt[k]);
                             v[k] = t;
+                            amax = fmaxf(amax, fabsf(t));
                         }
                         uint2 ph, plo;
                         lm_split4(v[0], v[1], v[2], v[3], &ph, &plo);
@@ -646,6 +651,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                         float t = fmaf(accm[mt][nt][4 * g4 + k], p.acc_scale, bb[k]);
                         if (bn) t = fmaf(fmaxf(t, 0.f), ss[k], tt[k]);
                         v[k] = t;
+                        amax = fmaxf(amax, fabsf(t));
                         if (!G16) pl[mg][k] = nt == 0 ? t : pl[mg][k] + t;
                     }
                     uint2 ph, plo;
@@ -694,6 +700,8 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                 }
             }
             }  // stored-output epilogue
+            // fmaxf drops a NaN operand, but a NaN can only come from an infinity that an earlier producer has flagged
+            if (p.range_flag != nullptr && !(amax < kF16Guard)) atomicOr(p.range_flag, 1u);
         }
         LM_TRACE_MARK(3);
         if (!have_next) break;
@@ -810,22 +818,24 @@ __global__ __launch_bounds__(256) void first_conv_h3_kernel(FirstConvParams p) {
     for (int k = 0; k < 9; ++k) wr[k] = wsm[k * 64 + lane];
     const float bias = p.bias[lane], s = p.bn_s[lane], sh = p.bn_t[lane];
     char* out = reinterpret_cast<char*>(p.out);
+    float amax = 0.f;  // f16 range guard
     for (int pix = 0; pix < 64; ++pix) {
         const int r = 4 * wave + (pix >> 4), c = pix & 15;
         float v = bias;
 #pragma unroll
         for (int k = 0; k < 9; ++k) v = fmaf(tile[(r + k / 3) * 18 + c + (k % 3)], wr[k], v);
         v = fmaf(fmaxf(v, 0.f), s, sh);
+        amax = fmaxf(amax, fabsf(v));
         const int y = y0 + r, x = x0 + c;
         if (y < p.H && x < p.W) {
             char* g = out + ((((size_t)b * p.H + y) * p.W + x) * p.out_cstride + p.out_coff) * 4 + (size_t)(lane >> 3) * 32 + (lane & 7) * 2;
             const lm_h16 h = lm_f2h(v);
             *reinterpret_cast<lm_h16*>(g) = h;
-            *reinterpret_cast<lm_h16*>(g + 16) = lm_f2h(v - lm_h2f(h));
+            *reinterpret_cast<lm_h16*>(g + 16) = lm_round_lo1(lm_f2h(v - lm_h2f(h)));
         }
     }
+    if (p.range_flag != nullptr && !(amax < kF16Guard)) atomicOr(p.range_flag, 1u);
 }
-
 hipError_t launch_first_conv_h3(const FirstConvParams& p, hipStream_t stream) {
     const int tiles = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH);
     LM_LAUNCH(first_conv_h3_kernel, dim3((unsigned)(tiles * p.B)), dim3(256), 0, stream, p);

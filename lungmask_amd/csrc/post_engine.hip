@@ -284,7 +284,7 @@ int inference(lm_engine* e, int slot, const void* vol, int dtype, int n, int h, 
             LM_K(launch_resample_norm(rp, e->stream));
         }
     }
-    LM_TRY(forward_batches(e, slot, a.xf.as<float>(), n, R, R, batch, a.labels.as<uint8_t>()));  // mask.py:173-187
+    LM_TRY(forward_guarded(e, slot, a.xf.as<float>(), n, R, R, batch, a.labels.as<uint8_t>(), nullptr));  // mask.py:173-187
     if (vol_post) LM_TRY(postprocess(e, a.labels.as<uint8_t>(), n, R, R, nullptr, 0, 3));  // mask.py:191-194
     ReshapeParams rs{a.labels.as<uint8_t>(), a.bbox.as<int>(), out, n, R, R, h, w};  // mask.py:196-202
     {

@@ -45,3 +45,42 @@ def test_fused_head_is_bit_identical_to_the_head_kernel(emu_engine, golden_dir):
         lab_fused = emu_engine.forward(0, x, want_logp=False)[0]
         lab_plain, logp = emu_engine.forward(0, x)
         assert np.array_equal(lab_fused, lab_plain) and np.array_equal(lab_plain, logp.argmax(1))
+
+
+def out_of_f16_range_state_dict(c=3, scale=1e5):
+    """A model whose FIRST layer's activations are ~1e5 (beyond the f16 maximum of 65504) while everything behind it is
+    ordinary: the first BatchNorm's affine is scaled up and the second conv's weights down by the same factor (the reference
+    computes this in fp32 without noticing)."""
+    import torch
+
+    sd = uo.synthetic_state_dict(c)
+    sd["down_path.0.block.2.weight"] = sd["down_path.0.block.2.weight"] * scale
+    sd["down_path.0.block.2.bias"] = sd["down_path.0.block.2.bias"] * scale
+    sd["down_path.0.block.3.weight"] = sd["down_path.0.block.3.weight"] / scale
+    return sd
+
+
+def test_f16_range_guard_falls_back_to_exact_fp32(emu_engine, golden_dir):
+    """Activations beyond the f16 range: the split-f16 kernels flag them, the engine re-runs the model on the exact-fp32
+    kernels in the same call and pins it there -- the result meets the 1e-3 bar instead of silently being wrong."""
+    import torch
+
+    g = np.load(os.path.join(golden_dir, "unet_c3.npz"))
+    x = g["rand32_x"][:1]
+    sd = out_of_f16_range_state_dict(3)
+    with torch.inference_mode():
+        ref = uo.forward(sd, torch.from_numpy(x if x.ndim == 4 else x[:, None])).numpy()
+    emu_engine.set_precision("split_f16")
+    emu_engine.load_state_dict(0, sd)
+    assert emu_engine.model_precision(0) == "split_f16"
+    lab, logp = emu_engine.forward(0, x)
+    assert emu_engine.model_precision(0) == "f32"  # the guard tripped and pinned the model
+    assert np.abs(logp - ref).max() < TOL
+    srt = np.sort(ref, axis=1)
+    assert not np.any((lab != ref.argmax(1)) & (srt[:, -1] - srt[:, -2] > 2 * TOL))
+    lab2 = emu_engine.forward(0, x, want_logp=False)[0]  # later forwards of this model: fp32 straight away
+    assert np.array_equal(lab2, lab)
+    # an ordinary model in the same engine keeps the fast path
+    emu_engine.load_state_dict(0, uo.synthetic_state_dict(3))
+    emu_engine.forward(0, x)
+    assert emu_engine.model_precision(0) == "split_f16"

@@ -243,8 +243,10 @@ def test_cli_npy_roundtrip(gpu_engine, tmp_path):
     assert main([str(ip), str(op), "--modelpath", str(wp), "--noprogress"]) == 0
     gpu_engine.load_state_dict(0, sd)
     assert np.array_equal(np.load(op), gpu_engine.apply(0, vol))
-    with pytest.raises(RuntimeError):
-        main([str(ip), str(op), "--modelpath", str(wp), "--cpu"])
+    # --cpu (reference __main__.py:81-83) is accepted: there is no CPU path, the same result comes from the GPU
+    op2 = tmp_path / "out_cpu_flag.npy"
+    assert main([str(ip), str(op2), "--modelpath", str(wp), "--cpu", "--noprogress"]) == 0
+    assert np.array_equal(np.load(op2), np.load(op))
 
 
 def test_apply_float_volume(gpu_engine):

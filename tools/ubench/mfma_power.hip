@@ -28,6 +28,8 @@ struct Fill {
     int relu_pct;  // % of activation values replaced by one constant (BatchNorm shift behind a ReLU)
     int zero;      // everything zero
     int lo_as_hi;  // 1: the "lo" operands are independent full-range values (three hi*hi products: the mfma_rate case)
+    int zero_pct;  // % of activation values that are exactly zero (a ReLU output stored WITHOUT the BatchNorm shift)
+    int order;     // 0: accumulators in rotation (shipped); 1: the three products of an accumulator back to back; 2: operands swapped
 };
 
 __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, int iters, Fill f) {
@@ -37,6 +39,7 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
             const unsigned id = (blockIdx.x * 512u + threadIdx.x) * 64u + j * 8 + i;
             float w = urand(id), a = urand(id ^ 0x9e3779b9u);
             if ((int)(urand(id ^ 0x51ed270bu) * 50.f + 50.f) < f.relu_pct) a = 0.117f;
+            if ((int)(urand(id ^ 0x2545f491u) * 50.f + 50.f) < f.zero_pct) a = 0.f;
             if (f.zero) w = a = 0.f;
             _Float16 wh = keep_bits((_Float16)w, f.hi_bits), ah = keep_bits((_Float16)a, f.hi_bits);
             _Float16 wl = (_Float16)(w - (float)wh), al = (_Float16)(a - (float)ah);
@@ -47,19 +50,51 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
         }
     f16v c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    for (int it = 0; it < iters; ++it) {
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[0], ahi[0], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[0], ahi[1], c1, 0, 0, 0);
-        c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[1], ahi[0], c2, 0, 0, 0);
-        c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[1], ahi[1], c3, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[0], alo[0], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[0], alo[1], c1, 0, 0, 0);
-        c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[1], alo[0], c2, 0, 0, 0);
-        c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[1], alo[1], c3, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[0], ahi[0], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[0], ahi[1], c1, 0, 0, 0);
-        c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[1], ahi[0], c2, 0, 0, 0);
-        c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[1], ahi[1], c3, 0, 0, 0);
+    if (f.order == 0) {
+        for (int it = 0; it < iters; ++it) {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[0], ahi[0], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[0], ahi[1], c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[1], ahi[0], c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[1], ahi[1], c3, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[0], alo[0], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[0], alo[1], c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[1], alo[0], c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[1], alo[1], c3, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[0], ahi[0], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[0], ahi[1], c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[1], ahi[0], c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[1], ahi[1], c3, 0, 0, 0);
+        }
+    } else if (f.order == 1) {
+        for (int it = 0; it < iters; ++it) {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[0], ahi[0], c0, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[0], alo[0], c0, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[0], ahi[0], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[0], ahi[1], c1, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[0], alo[1], c1, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[0], ahi[1], c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[1], ahi[0], c2, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[1], alo[0], c2, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[1], ahi[0], c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[1], ahi[1], c3, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[1], alo[1], c3, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[1], ahi[1], c3, 0, 0, 0);
+        }
+    } else {
+        for (int it = 0; it < iters; ++it) {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[0], whi[0], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[1], whi[0], c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[0], whi[1], c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[1], whi[1], c3, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[0], whi[0], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[1], whi[0], c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[0], whi[1], c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[1], whi[1], c3, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[0], wlo[0], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[1], wlo[0], c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[0], wlo[1], c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[1], wlo[1], c3, 0, 0, 0);
+        }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float s = 0;
@@ -78,17 +113,22 @@ int main() {
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
     struct { const char* name; Fill f; } cases[] = {
-        {"zeros", {10, 10, 0, 1, 0}},
-        {"three independent full-range products", {10, 10, 0, 0, 1}},
-        {"split, lo = all 10 mantissa bits (shipped)", {10, 10, 0, 0, 0}},
-        {"split, lo keeps 8 mantissa bits", {10, 8, 0, 0, 0}},
-        {"split, lo keeps 6 mantissa bits", {10, 6, 0, 0, 0}},
-        {"split, lo keeps 4 mantissa bits", {10, 4, 0, 0, 0}},
-        {"split, lo keeps 2 mantissa bits", {10, 2, 0, 0, 0}},
-        {"split, lo = 0", {10, -1, 0, 0, 0}},
-        {"split, hi keeps 7 bits (bf16-like), lo all", {7, 10, 0, 0, 0}},
-        {"split (lo all), 50% of activations constant", {10, 10, 50, 0, 0}},
-        {"split (lo 4 bits), 50% of activations constant", {10, 4, 50, 0, 0}},
+        {"zeros", {10, 10, 0, 1, 0, 0, 0}},
+        {"three independent full-range products", {10, 10, 0, 0, 1, 0, 0}},
+        {"split, lo = all 10 mantissa bits (shipped)", {10, 10, 0, 0, 0, 0, 0}},
+        {"split, lo keeps 8 mantissa bits", {10, 8, 0, 0, 0, 0, 0}},
+        {"split, lo keeps 6 mantissa bits", {10, 6, 0, 0, 0, 0, 0}},
+        {"split, lo keeps 4 mantissa bits", {10, 4, 0, 0, 0, 0, 0}},
+        {"split, lo keeps 2 mantissa bits", {10, 2, 0, 0, 0, 0, 0}},
+        {"split, lo = 0", {10, -1, 0, 0, 0, 0, 0}},
+        {"split, hi keeps 7 bits (bf16-like), lo all", {7, 10, 0, 0, 0, 0, 0}},
+        {"split (lo all), 50% of activations constant", {10, 10, 50, 0, 0, 0, 0}},
+        {"split (lo 4 bits), 50% of activations constant", {10, 4, 50, 0, 0, 0, 0}},
+        {"split (lo all), 50% of activations ZERO", {10, 10, 0, 0, 0, 50, 0}},
+        {"split (lo all), 70% of activations ZERO", {10, 10, 0, 0, 0, 70, 0}},
+        {"split (lo 6 bits), 50% of activations ZERO", {10, 6, 0, 0, 0, 50, 0}},
+        {"split (lo all), 3 products of an accumulator back to back", {10, 10, 0, 0, 0, 0, 1}},
+        {"split (lo all), activations as the A operand", {10, 10, 0, 0, 0, 0, 2}},
     };
     for (auto& c : cases) {
         int iters = 4000;
@@ -106,7 +146,7 @@ int main() {
         double avg = 0;
         for (int i = 0; i < blocks; ++i) avg += (double)cy[i] / blocks;
         const double flop = (double)blocks * (threads / 64) * iters * 12.0 * 32768.0;
-        printf("%-48s %8.1f TFLOP/s  clock %.3f GHz\n", c.name, flop / ms / 1e9, avg / (ms * 1e6));
+        printf("%-62s %8.1f TFLOP/s  clock %.3f GHz\n", c.name, flop / ms / 1e9, avg / (ms * 1e6));  // s_memtime ticks per wall time
     }
     return 0;
 }
