@@ -22,22 +22,36 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
 PEAK_F16_MFMA_TFLOPS = 2500.0  # same table: Peak BF16/FP16 MFMA, dense
-FLOP_PER_SLICE = 96.200556544e9  # R231, SURVEY.md Appendix A (algorithmic, 256x256)
+# What the matrix pipes SUSTAIN on this network's operand statistics (tools/ubench/mfma_power.hip, the conv kernel's own
+# instruction pattern on full-range split operands, no memory traffic at all): the chip clocks to its power budget, 2.37 GHz
+# on zeros but ~1.6 GHz on real data.  profiles/r02d_mfma_power.log
+SUSTAINED_F16_MFMA_TFLOPS = 1737.0
+# algorithmic FLOP per slice, SURVEY.md Appendix A (256x256): R231 (3 classes), LTRCLobes (6 classes)
+FLOP_PER_SLICE = {3: 96.200556544e9, 6: 96.225722368e9}
+CONFIGS = {  # BASELINE.json configs[1..3]
+    2: ("R231 U-Net", 3, None),
+    3: ("LTRCLobes 6-class U-Net", 6, None),
+    4: ("LTRCLobes_R231 fused mode (LTRCLobes + R231 fill model, label fusion, full-resolution post-processing)", 6, 3),
+}
 
 
 def pmc_traffic(kernel_substr):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this same
-    command (tools/summarize_prof.py -> profiles/rNN_pmc.json); None when no summary is present."""
+    """HBM bytes per launch of the dominant kernel, launch-weighted over every instantiation whose name contains
+    `kernel_substr`, from the LATEST COMMITTED rocprofv3 PMC summary of this same command (tools/summarize_prof.py ->
+    profiles/rNN_pmc.json).  It is read from that file, not measured in this run; (None, None) when there is no summary."""
     import glob
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
     if not files:
-        return None
+        return None, None
     d = json.load(open(files[-1]))
+    tot = n = 0.0
     for k, v in d.get("kernels", {}).items():
         if kernel_substr in k and "hbm_bytes_per_launch_corrected" in v:
-            return v["hbm_bytes_per_launch_corrected"]
-    return None
+            w = float(v.get("launches_FETCH_SIZE", 1))
+            tot += v["hbm_bytes_per_launch_corrected"] * w
+            n += w
+    return (tot / n if n else None), os.path.relpath(files[-1], ROOT)
 
 
 def cpu_baseline(n_sample, sd):
@@ -88,7 +102,12 @@ def main():
     ap.add_argument("--precision", default="split_f16", choices=["split_f16", "f32"])
     ap.add_argument("--post", default="slab", choices=["slab", "gathered"], help="N>1 post-processing: slab-sharded (default) or label all-gather + redundant whole-volume pass")
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2], help="forward lanes (2: consecutive batches overlap on two streams)")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4], help="BASELINE.json configuration: 2 R231 (the headline), 3 LTRCLobes, 4 LTRCLobes_R231 fused")
+    ap.add_argument("--host-steps", type=int, default=3, help="untimed-by-the-contract extra steps numpy -> numpy (lm_apply_host) for value_host_to_host; 0 to skip")
     args = ap.parse_args()
+    cfg_name, n_classes, fill_classes = CONFIGS[args.config]
+    if args.gpus > 1 and args.config != 2:
+        raise SystemExit("configs 3 and 4 are single-GPU configurations (BASELINE.json)")
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -115,15 +134,22 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     eng = nat.Engine(local_rank)  # raises if liblungmask_hip.so or the GPU is missing: no fallback
-    weights = "synthetic (lungmask_amd.synthetic.synthetic_state_dict, seed 231)"
-    sd = None
     wd = os.environ.get("LUNGMASK_WEIGHTS_DIR")
-    if wd and os.path.exists(os.path.join(wd, "unet_r231-d5d2fc3d.pth")):
-        sd = torch.load(os.path.join(wd, "unet_r231-d5d2fc3d.pth"), map_location="cpu")
-        weights = "pretrained unet_r231-d5d2fc3d.pth"
-    if sd is None:
-        sd = uo.synthetic_state_dict(3)
+    pth = {3: "unet_r231-d5d2fc3d.pth", 6: "unet_ltrclobes-3a07043d.pth"}
+
+    def load(c):
+        if wd and os.path.exists(os.path.join(wd, pth[c])):
+            return torch.load(os.path.join(wd, pth[c]), map_location="cpu"), "pretrained " + pth[c]
+        return uo.synthetic_state_dict(c), f"synthetic (lungmask_amd.synthetic.synthetic_state_dict({c}), seed 231)"
+
+    sd, weights = load(n_classes)
     eng.load_state_dict(0, sd)
+    fill_slot = -1
+    if fill_classes is not None:
+        sd_fill, w2 = load(fill_classes)
+        eng.load_state_dict(1, sd_fill)
+        weights += " + fill model: " + w2
+        fill_slot = 1
     eng.set_precision(args.precision)
     eng.set_streams(args.streams)
 
@@ -143,7 +169,7 @@ def main():
         od = eng.empty(vol.shape, np.uint8)
 
         def step():
-            eng.apply_dev(0, vd, od, batch_size=args.batch)
+            eng.apply_dev(0, vd, od, fill_slot=fill_slot, batch_size=args.batch)
     else:
         from lungmask_amd.pipeline import ShardedPipeline
 
@@ -185,6 +211,21 @@ def main():
     if args.streams == 1:
         stats = stats or solo
 
+    # numpy in -> numpy out (lm_apply_host: H2D of the volume, the same hot path, D2H of the labels): what a caller of
+    # LMInferer.apply(ndarray) sees.  Reported beside `value`, never as `value` (the timed region above starts with the
+    # volume resident in HBM).
+    host = None
+    if not use_dist and args.host_steps > 0:
+        eng.apply(0, vol, fill_slot=fill_slot, batch_size=args.batch)
+        eng.sync()
+        t0h = time.perf_counter()
+        for _ in range(args.host_steps):
+            res_h = eng.apply(0, vol, fill_slot=fill_slot, batch_size=args.batch)
+        dth = (time.perf_counter() - t0h) / args.host_steps
+        host = {"value": round(n_total / dth, 2), "unit": "slices/s", "ms_per_step": round(dth * 1e3, 3), "steps": args.host_steps,
+                "note": "numpy int16 volume in host memory -> uint8 numpy labels in host memory (lm_apply_host), PCIe copies included; "
+                        "identical labels: " + str(bool(np.array_equal(res_h, od.download())))}
+
     if rank == 0:
         value = n_total * args.steps / dt
         h3 = args.precision == "split_f16"
@@ -203,6 +244,7 @@ def main():
         if conv and conv["total_ms"] > 0:
             ach = conv["flops"] / (conv["total_ms"] * 1e-3) / 1e12
             peak = PEAK_F16_MFMA_TFLOPS if h3 else PEAK_F32_MFMA_TFLOPS
+            traffic, traffic_src = pmc_traffic("conv_igemm_h3p<9" if h3 else "conv_igemm_f32<9")
             roof = {
                 "bound": "mfma",
                 "kernel": kname + (" (v_mfma_f32_32x32x16_f16, 3-product split-f16: 3 executed MFMA FLOPs per algorithmic FLOP)" if h3
@@ -213,8 +255,14 @@ def main():
                 "frac": round(ach / peak, 4),
                 "executed_mfma_tflops": round(ach * (3 if h3 else 1), 2),
                 "executed_frac_of_peak": round(ach * (3 if h3 else 1) / peak, 4),
-                "traffic": pmc_traffic("conv_igemm_h3p<9" if h3 else "conv_igemm_f32<9"),
-                "traffic_unit": "bytes/launch (rocprofv3 PMC, separate FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected; profiles/*_pmc.json)",
+                "sustained_mfma_ceiling_tflops": SUSTAINED_F16_MFMA_TFLOPS if h3 else None,
+                "executed_frac_of_sustained_ceiling": round(ach * 3 / SUSTAINED_F16_MFMA_TFLOPS, 4) if h3 else None,
+                "ceiling_note": "the data sheet peak assumes 2.4 GHz; on full-range operands the matrix pipes alone (no memory traffic) sustain "
+                                "1737 TFLOP/s at ~1.6 GHz under the power budget (tools/ubench/mfma_power.hip, profiles/r02d_mfma_power.log)" if h3 else None,
+                "traffic": traffic,
+                "traffic_unit": "HBM bytes/launch, launch-weighted over the same 17 launches per batch as algorithmic_bytes_per_launch; NOT measured in this "
+                                f"run: read from the committed rocprofv3 PMC summary {traffic_src} (separate FETCH_SIZE / WRITE_SIZE passes of "
+                                "`bench.py --streams 1`, gfx950-corrected)" if traffic is not None else "no committed PMC summary",
                 "algorithmic_bytes_per_launch": conv["bytes"] / conv["launches"],
                 "launches": conv["launches"],
                 "avg_launch_ms": round(conv["total_ms"] / conv["launches"], 4),
@@ -226,7 +274,7 @@ def main():
                 "overlapped": overlapped,
             }
         out = {
-            "metric": "CT slices/sec (whole node), R231 512x512 volume",
+            "metric": "CT slices/sec (whole node), R231 512x512 volume" if args.config == 2 else f"CT slices/sec, {cfg_name}, 512x512 volume",
             "value": round(value, 2),
             "unit": "slices/s",
             "n_gpus": world,
@@ -239,12 +287,14 @@ def main():
             "dtype": "f16x3-split (hi/lo f16 operands, f32 accumulate; fp32-class)" if h3 else "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"R231 U-Net, 512x512x{n_local} int16 HU phantom per GPU ({n_total} slices total), batchsize={args.batch}, "
-                            "LMInferer.apply device-resident (pre + forward + argmax + 3-D post + un-crop)",
+                "workload": f"BASELINE.json configs[{args.config - 1}]: {cfg_name}, 512x512x{n_local} int16 HU phantom per GPU ({n_total} slices total), "
+                            f"batchsize={args.batch}, LMInferer.apply device-resident (pre + forward + argmax + 3-D post + un-crop"
+                            + (" + second model + fusion + full-resolution post" if fill_slot >= 0 else "") + ")",
                 "weights": weights,
                 "parallelism": "single GPU" if not use_dist else (f"slice-sharded x{world}: slab-local post-processing + 6 small RCCL table all-gathers, 1 all-gather of the output" if args.post == "slab" else f"slice-sharded x{world}: RCCL all-gather of the labels, redundant whole-volume post-processing, all-gather of the output"),
             },
-            "end_to_end_tflops": round(value * FLOP_PER_SLICE / 1e12, 2),
+            "end_to_end_tflops": round(value * (FLOP_PER_SLICE[n_classes] + (FLOP_PER_SLICE[fill_classes] if fill_classes else 0.0)) / 1e12, 2),
+            "value_host_to_host": host,
             "roofline": roof,
             "stages_ms_per_step": {s["name"]: round(s["total_ms"], 3) for s in solo},
             "stages_note": "HIP-event time per kernel kind of ONE step, from the untimed single-lane pass after the timed region",

@@ -58,6 +58,11 @@ int lm_engine_create(lm_engine** out, int device_id);
 void lm_engine_destroy(lm_engine* e);
 int lm_engine_sync(lm_engine* e);
 
+/* The HIP stream (hipStream_t, as void*) every stage call of this engine enqueues on.  A host that owns other GPU work or
+ * collectives (lungmask_amd/pipeline.py: torch.distributed over RCCL) orders them against the engine's kernels by enqueuing on
+ * / waiting for this stream instead of synchronising the device.  NULL for a NULL engine. */
+void* lm_engine_stream(lm_engine* e);
+
 /* ---- device memory helpers (so a binding needs no other GPU runtime) ---------- */
 int lm_dev_alloc(lm_engine* e, void** dev_ptr, size_t bytes);
 int lm_dev_free(lm_engine* e, void* dev_ptr);

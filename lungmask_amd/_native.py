@@ -62,6 +62,8 @@ class Library:
         L.lm_copy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.lm_model_load.argtypes = [C.c_void_p, C.c_int, C.POINTER(_Tensor), C.c_int]
         L.lm_model_classes.argtypes = [C.c_void_p, C.c_int]
+        L.lm_engine_stream.argtypes = [C.c_void_p]
+        L.lm_engine_stream.restype = C.c_void_p
         L.lm_model_precision.argtypes = [C.c_void_p, C.c_int]
         L.lm_forward_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.lm_set_precision.argtypes = [C.c_void_p, C.c_int]
@@ -192,6 +194,10 @@ class Engine:
         keep.append((names, arrs))
         self.L.check(self.L.lib.lm_model_load(self.h, slot, tens, len(arrs)), "lm_model_load")
         return self.L.check(self.L.lib.lm_model_classes(self.h, slot))
+
+    def stream_handle(self) -> int:
+        """hipStream_t of the engine as an integer (0 under emulation): see lm_engine_stream in include/lungmask_hip.h."""
+        return int(self.L.lib.lm_engine_stream(self.h) or 0)
 
     def n_classes(self, slot: int) -> int:
         return self.L.check(self.L.lib.lm_model_classes(self.h, slot), "lm_model_classes")

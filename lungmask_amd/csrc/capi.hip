@@ -1,5 +1,8 @@
 // extern "C" surface of liblungmask_hip.so (include/lungmask_hip.h).
 #include "engine.h"
+#ifndef LM_EMU_BUILD
+#include <thread>
+#endif
 #include "post_kernels.h"
 #include "pre_kernels.h"
 
@@ -71,6 +74,8 @@ void lm_engine_destroy(lm_engine* e) {
     if (e->stream2) (void)hipStreamSynchronize(e->stream2);
     if (e->zero_page) (void)hipFree(e->zero_page);
     if (e->range_flag_host) (void)hipHostFree(e->range_flag_host);
+    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+    if (e->tail_ready) (void)hipEventDestroy(e->tail_ready);
     e->nn.release();
     e->nn2.release();
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
@@ -120,6 +125,8 @@ int lm_model_load(lm_engine* e, int slot, const lm_tensor* tensors, int n_tensor
     LM_HIP(hipSetDevice(e->device));
     return model_load(e, slot, tensors, n_tensors);
 }
+void* lm_engine_stream(lm_engine* e) { return e ? reinterpret_cast<void*>(e->stream) : nullptr; }
+
 int lm_model_classes(lm_engine* e, int slot) {
     if (!e || slot < 0 || slot >= 4 || !e->models[slot].loaded) return LM_ERR_NOMODEL;
     return e->models[slot].n_classes;
@@ -326,11 +333,55 @@ int lm_apply_host(lm_engine* e, int slot, int fill_slot, const void* vol_host, i
         return LM_ERR_INVALID;
     }
     LM_DEVICE(e);
-    const size_t nvox = (size_t)n * h * w;
+    const size_t nvox = (size_t)n * h * w, slice = (size_t)h * w;
     LM_TRY(e->app.vol.reserve(nvox * esz));
     LM_TRY(e->app.out.reserve(nvox));
+    // mask.py:178-186 moves every batch to the device and back on its own; here the boundary is crossed once per volume, in two
+    // pieces.  The head (two batches) goes in on the main stream, and while it is pre-processed and run through the network a
+    // helper thread (a) copies the tail in on a second stream and (b) touches every page of the caller's output array, so that
+    // the copy back at the end does not take the page faults of a freshly allocated buffer.
+    if (batch_size <= 0) batch_size = 20;
+    const int head = (e->n_streams > 1 ? 2 : 1) * batch_size;
+    const bool split = n > head;
+#ifndef LM_EMU_BUILD
+    if (split && !e->copy_stream) {
+        if (hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->tail_ready, hipEventDisableTiming) != hipSuccess) {
+            set_error("lm_apply_host: creating the copy stream failed");
+            return LM_ERR_DEVICE;
+        }
+    }
+    e->tail_enqueued.store(0, std::memory_order_release);
+    std::thread helper([&] {
+        hipError_t terr = hipSuccess;
+        if (split) {
+            terr = hipSetDevice(e->device);
+            // (a pageable source makes this call return only when the data has been staged: that is why it lives on this thread)
+            if (terr == hipSuccess)
+                terr = hipMemcpyAsync(reinterpret_cast<char*>(e->app.vol.p) + (size_t)head * slice * esz, reinterpret_cast<const char*>(vol_host) + (size_t)head * slice * esz,
+                                      (size_t)(n - head) * slice * esz, hipMemcpyHostToDevice, e->copy_stream);
+            if (terr == hipSuccess) terr = hipEventRecord(e->tail_ready, e->copy_stream);
+        }
+        e->tail_enqueued.store(terr == hipSuccess ? 1 : -1, std::memory_order_release);
+        volatile uint8_t* o = out_host;
+        for (size_t i = 0; i < nvox; i += 4096) o[i] = 0;
+        if (nvox) o[nvox - 1] = 0;
+    });
+    hipError_t err = hipMemcpyAsync(e->app.vol.p, vol_host, (size_t)std::min(n, head) * slice * esz, hipMemcpyHostToDevice, e->stream);
+    int rc = LM_OK;
+    if (err != hipSuccess) {
+        set_error("lm_apply_host: host-to-device copy failed: %s", hipGetErrorString(err));
+        rc = LM_ERR_DEVICE;
+    } else {
+        e->head_slices = split ? head : 0;
+        rc = apply_volume(e, slot, fill_slot, e->app.vol.p, dtype, n, h, w, batch_size, volume_postprocessing, e->app.out.as<uint8_t>());
+        e->head_slices = 0;
+    }
+    helper.join();
+    if (rc != LM_OK) return rc;
+#else
     LM_HIP(hipMemcpyAsync(e->app.vol.p, vol_host, nvox * esz, hipMemcpyHostToDevice, e->stream));
     LM_TRY(apply_volume(e, slot, fill_slot, e->app.vol.p, dtype, n, h, w, batch_size, volume_postprocessing, e->app.out.as<uint8_t>()));
+#endif
     LM_HIP(hipMemcpyAsync(out_host, e->app.out.p, nvox, hipMemcpyDeviceToHost, e->stream));
     LM_HIP(hipStreamSynchronize(e->stream));
     return LM_OK;

@@ -1,5 +1,6 @@
 // Host-side engine state behind the C ABI (include/lungmask_hip.h).
 #pragma once
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <map>
@@ -161,6 +162,15 @@ struct lm_engine {
     lm::Profiler prof;
     int precision = 1;  // 1 (default): split-f16 3-product; 0: exact fp32 matrix ops (lm_set_precision)
     char* zero_page = nullptr;
+    // lm_apply_host: the volume arrives in two pieces (the first two batches on the main stream, the rest on copy_stream while
+    // they are computed); `tail_ready` is recorded behind the second piece, the hot path waits for it before it touches
+    // slices >= head_slices.  head_slices == 0: the whole volume is already resident (lm_apply_dev).
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t tail_ready = nullptr;
+    int head_slices = 0;
+    // set by the copying thread once tail_ready has been recorded (1) or the copy failed (-1): the hot path must not enqueue
+    // its wait on an event that has not been recorded yet (that would be a no-op)
+    std::atomic<int> tail_enqueued{0};
     unsigned* range_flag = nullptr;       // device word of the f16 range guard (ConvParamsH3::range_flag)
     unsigned* range_flag_host = nullptr;  // pinned copy
 };

@@ -15,6 +15,8 @@
 #include <cstring>
 #include <numeric>
 
+#include <thread>
+
 #include "engine.h"
 #include "post_kernels.h"
 #include "pre_kernels.h"
@@ -271,20 +273,36 @@ int inference(lm_engine* e, int slot, const void* vol, int dtype, int n, int h, 
     LM_TRY(a.xf.reserve((size_t)n * R * R * 4));
     LM_TRY(a.bbox.reserve((size_t)n * 16));
     LM_TRY(a.labels.reserve((size_t)n * R * R));
-    if (!have_pre) {  // mask.py:166-168
-        BodyMaskParams bp{vol, dtype, n, h, w, a.bbox.as<int>(), nullptr};
-        const int esz = dtype == LM_I16 ? 2 : ((dtype == LM_I32 || dtype == LM_F32) ? 4 : 8);
-        {
-            ProfScope ps(e, "bodymask_bbox", (double)n * 128 * 128 * esz);
-            LM_K(launch_bodymask_bbox(bp, e->stream));
+    // Slices are independent up to the argmax (mask.py:166-187), so the volume is worked on in up to two pieces: when
+    // lm_apply_host is still copying the tail of the volume in (engine.h: head_slices / tail_ready), the head's pre-processing
+    // and forward run meanwhile.
+    const int esz = dtype == LM_I16 ? 2 : ((dtype == LM_I32 || dtype == LM_F32) ? 4 : 8);
+    const int head = (e->head_slices > 0 && e->head_slices < n) ? e->head_slices : n;
+    for (int s0 = 0; s0 < n; s0 += (s0 == 0 ? head : n)) {
+        const int ns = s0 == 0 ? head : n - s0;
+        if (s0 > 0) {
+            while (e->tail_enqueued.load(std::memory_order_acquire) == 0) std::this_thread::yield();  // normally long done: the head took milliseconds
+            if (e->tail_enqueued.load(std::memory_order_acquire) < 0) {
+                set_error("lm_apply_host: copying the volume to the device failed");
+                return LM_ERR_DEVICE;
+            }
+            LM_HIP(hipStreamWaitEvent(e->stream, e->tail_ready, 0));
         }
-        ResampleParams rp{vol, dtype, n, h, w, a.bbox.as<int>(), R, R, nullptr, a.xf.as<float>()};
-        {
-            ProfScope ps(e, "resample_norm", (double)n * h * w * esz + (double)n * R * R * 4);
-            LM_K(launch_resample_norm(rp, e->stream));
+        if (!have_pre) {  // mask.py:166-168
+            const char* v = reinterpret_cast<const char*>(vol) + (size_t)s0 * h * w * esz;
+            BodyMaskParams bp{v, dtype, ns, h, w, a.bbox.as<int>() + (size_t)s0 * 4, nullptr};
+            {
+                ProfScope ps(e, "bodymask_bbox", (double)ns * 128 * 128 * esz);
+                LM_K(launch_bodymask_bbox(bp, e->stream));
+            }
+            ResampleParams rp{v, dtype, ns, h, w, a.bbox.as<int>() + (size_t)s0 * 4, R, R, nullptr, a.xf.as<float>() + (size_t)s0 * R * R};
+            {
+                ProfScope ps(e, "resample_norm", (double)ns * h * w * esz + (double)ns * R * R * 4);
+                LM_K(launch_resample_norm(rp, e->stream));
+            }
         }
+        LM_TRY(forward_guarded(e, slot, a.xf.as<float>() + (size_t)s0 * R * R, ns, R, R, batch, a.labels.as<uint8_t>() + (size_t)s0 * R * R, nullptr));  // mask.py:173-187
     }
-    LM_TRY(forward_guarded(e, slot, a.xf.as<float>(), n, R, R, batch, a.labels.as<uint8_t>(), nullptr));  // mask.py:173-187
     if (vol_post) LM_TRY(postprocess(e, a.labels.as<uint8_t>(), n, R, R, nullptr, 0, 3));  // mask.py:191-194
     ReshapeParams rs{a.labels.as<uint8_t>(), a.bbox.as<int>(), out, n, R, R, h, w};  // mask.py:196-202
     {

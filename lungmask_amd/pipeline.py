@@ -18,8 +18,13 @@ result on every rank (79 MB per rank at 300 slices/rank; xGMI is point-to-point 
 connected inside a node, so it is single-step and per-link bound, well under a millisecond).
 
 All buffers are torch tensors (device memory + collectives are torch's job here,
-nothing else); the engine receives raw pointers.  In the CPU test-suite the tensors
-are host tensors, the backend is gloo and the engine is the test emulation.
+nothing else); the engine receives raw pointers.  On the GPU the engine's own HIP stream
+(`lm_engine_stream`) is made torch's current stream for everything in here, so the RCCL
+collectives are ordered against the engine's kernels by stream dependencies (torch's
+process group waits for the current stream before a collective and lets it wait for the
+collective afterwards): the host only blocks where it needs data -- the three table merges
+of the slab protocol.  In the CPU test-suite the tensors are host tensors, the backend is
+gloo and the engine is the test emulation.
 """
 from __future__ import annotations
 
@@ -56,6 +61,15 @@ class ShardedPipeline:
         self.rank = dist.get_rank() if dist is not None else 0
         self.sharded_post = bool(sharded_post)
         self._buf = {}
+        # the engine's stream as torch's current stream (see the module docstring); None on the CPU / under emulation
+        self._stream = None
+        if self.device.type == "cuda" and engine.stream_handle():
+            self._stream = torch.cuda.ExternalStream(engine.stream_handle(), device=self.device)
+
+    def _on_engine_stream(self):
+        import contextlib
+
+        return torch.cuda.stream(self._stream) if self._stream is not None else contextlib.nullcontext()
 
     def _tensor(self, key, shape, dtype):
         t = self._buf.get(key)
@@ -70,13 +84,19 @@ class ShardedPipeline:
             torch.cuda.synchronize(self.device)
 
     def _all_gather(self, out: torch.Tensor, mine: torch.Tensor):
-        # gloo must not alias input and output; RCCL gathers in place
+        # gloo must not alias input and output; RCCL gathers in place.  Called with the engine's stream current: no host
+        # synchronisation here (without that stream, e.g. an engine of another build, fall back to a device sync)
         self.dist.all_gather_into_tensor(out, mine.clone() if self.device.type == "cpu" else mine)
-        self._sync_torch()
+        if self._stream is None:
+            self._sync_torch()
 
     def postprocess_slab(self, lab_slab: torch.Tensor, z0: int, n_total: int, spare: Sequence[int] = (), skip_below: int = 3):
         """utils.postprocessing over a volume whose slices are spread over the ranks; `lab_slab` (uint8 [n_r,h,w], n_r >= 1,
         slices [z0, z0+n_r)) is processed IN PLACE.  Protocol of include/lungmask_hip.h (lm_slab_*)."""
+        with self._on_engine_stream():
+            return self._postprocess_slab(lab_slab, z0, n_total, spare, skip_below)
+
+    def _postprocess_slab(self, lab_slab, z0, n_total, spare, skip_below):
         e, lib = self.e, self.e.L.lib
         n_r, h, w = (int(v) for v in lab_slab.shape)
         sp = (C.c_int * max(len(spare), 1))(*[int(v) for v in spare])
@@ -107,6 +127,15 @@ class ShardedPipeline:
     def apply(self, volume: np.ndarray) -> np.ndarray:
         """Convenience form of `LMInferer.apply` for a process group: every rank passes the SAME host volume [n,h,w] (int16),
         works on its own block of slices and returns the complete uint8 label volume."""
+        volume = np.asarray(volume)
+        if volume.dtype != np.int16:
+            # this entry point shards int16 HU volumes (what DICOM / the bench phantom give); other integer types are accepted
+            # when their values fit -- never wrapped -- and everything else belongs to LMInferer.apply (float volumes, fusion
+            # with a fill model and image orientation are not part of the sharded form)
+            if volume.dtype.kind not in "iu":
+                raise TypeError(f"ShardedPipeline.apply: integer HU volume expected, got {volume.dtype} (use LMInferer.apply)")
+            if volume.size and (volume.min() < -32768 or volume.max() > 32767):
+                raise ValueError("ShardedPipeline.apply: values outside the int16 range (use LMInferer.apply)")
         vol = np.ascontiguousarray(volume, dtype=np.int16)
         n_total = int(vol.shape[0])
         b = shard_bounds(n_total, self.world)
@@ -133,13 +162,18 @@ class ShardedPipeline:
         assert vol_shard.dtype == torch.int16 and vol_shard.is_contiguous()
         oh, ow = self.res
         xf = self._tensor("xf", (max(n_r, 1), oh, ow), torch.float32)
-        self._sync_torch()
+        self._sync_torch()  # the caller's shard (copied in on another stream) is complete
         # ---- sliced stages: no communication
         if n_r:
             e.L.check(lib.lm_preprocess_dev(e.h, vol_shard.data_ptr(), 0, n_r, h, w, oh, ow, bbox.data_ptr(), xf.data_ptr(), None, None), "lm_preprocess_dev")
             e.L.check(lib.lm_forward_batches_dev(e.h, self.slot, xf.data_ptr(), n_r, oh, ow, self.batch_size, lab_loc.data_ptr()), "lm_forward_batches_dev")
-        e.sync()
-        return self.assemble(n_total, h, w)
+        if self._stream is None:
+            e.sync()
+        with self._on_engine_stream():
+            out = self.assemble(n_total, h, w)
+        if self._stream is not None:
+            self._stream.synchronize()  # the result is complete when this returns (as before)
+        return out
 
     def assemble(self, n_total: int, h: int, w: int) -> torch.Tensor:
         """Everything after the argmax: volume post-processing of the label shards in `shard_buffers(n_total)`, un-crop with
@@ -166,7 +200,8 @@ class ShardedPipeline:
                     full = lab_all
             else:
                 full = lab_all[:n_r]
-            self._sync_torch()
+            if self._stream is None:
+                self._sync_torch()
             if self.volume_postprocessing and n_total:
                 e.L.check(lib.lm_postprocess_dev(e.h, full.data_ptr(), n_total, oh, ow, None, 0, 3), "lm_postprocess_dev")
             mine_lab = full[bounds[self.rank] : bounds[self.rank + 1]]
@@ -175,7 +210,8 @@ class ShardedPipeline:
         out_loc = out_all[self.rank * maxc : (self.rank + 1) * maxc]
         if n_r:
             e.L.check(lib.lm_reshape_mask_dev(e.h, mine_lab.data_ptr(), bbox.data_ptr(), n_r, oh, ow, h, w, out_loc.data_ptr()), "lm_reshape_mask_dev")
-        e.sync()
+        if self._stream is None:
+            e.sync()
         # ---- exchange #2: output shards
         if self.dist is not None:
             self._all_gather(out_all.view(-1), out_loc.reshape(-1))

@@ -67,6 +67,30 @@ def test_ref_known_answers_postprocessing():
     assert po.postprocessing(t, spare=[3], skip_below=3)[0][2, 1] == 0  # :156-159
 
 
+def test_postprocessing_fast_is_the_same_function():
+    """`postprocessing_fast` (per-region passes confined to tracked bounding boxes, one-pass hole fill) against the
+    statement-by-statement `postprocessing`: random multi-label volumes with noise, spare labels, both skip_below values."""
+    rng = np.random.default_rng(3)
+    for case in range(24):
+        shape = (int(rng.integers(2, 12)), int(rng.integers(10, 40)), int(rng.integers(10, 40)))
+        v = np.zeros(shape, np.uint8)
+        for _ in range(int(rng.integers(3, 30))):
+            c = [int(rng.integers(0, s)) for s in shape]
+            r = [int(rng.integers(1, max(2, s // 4))) for s in shape]
+            v[tuple(slice(max(0, ci - ri), ci + ri) for ci, ri in zip(c, r))] = rng.integers(1, 5)
+        if case % 4 == 0:
+            noise = rng.random(shape) < 0.05
+            v[noise] = rng.integers(1, 4, size=int(noise.sum()))
+        for spare in ([], [int(v.max())]):
+            for sb in (1, 3):
+                assert np.array_equal(po.postprocessing(v.copy(), spare=spare, skip_below=sb), po.postprocessing_fast(v.copy(), spare=spare, skip_below=sb)), (case, spare, sb)
+    for _ in range(10):
+        x = rng.random((int(rng.integers(2, 10)), 30, 30)) < 0.45
+        assert np.array_equal(po.fill_voids_fill(x), po.fill_voids_fill_fast(x))
+    t = np.zeros((1, 6, 6), dtype=np.uint8)
+    assert np.array_equal(po.postprocessing(t), po.postprocessing_fast(t))  # N == 1 and empty
+
+
 def test_prepost_oracle_vs_reference_goldens(gpp):
     g = gpp
     for i in range(int(g["n_pre"])):
@@ -79,6 +103,8 @@ def test_prepost_oracle_vs_reference_goldens(gpp):
     for i in range(int(g["n_post"])):
         out = po.postprocessing(g[f"post{i}_lab"].copy(), [int(x) for x in g[f"post{i}_spare"]], int(g[f"post{i}_skip"]))
         assert np.array_equal(out, g[f"post{i}_out"]), i
+        fast = po.postprocessing_fast(g[f"post{i}_lab"].copy(), [int(x) for x in g[f"post{i}_spare"]], int(g[f"post{i}_skip"]))
+        assert np.array_equal(fast, g[f"post{i}_out"]), i  # the bounding-box form used at full volume size
     for i in range(int(g["n_rs"])):
         out = po.reshape_mask(g[f"rs{i}_mask"], [int(x) for x in g[f"rs{i}_box"]], tuple(int(x) for x in g[f"rs{i}_osz"]))
         assert np.array_equal(out.astype(np.uint8), g[f"rs{i}_out"]), i

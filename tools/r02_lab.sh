@@ -1,6 +1,9 @@
-# Round-2 lab run (measurement only, not the product)
-TAG=${1:-r02c}
-timeout 200 python tools/nn_perf3.py > gpurun_out/${TAG}_nn_perf3.log 2>&1; grep batch gpurun_out/${TAG}_nn_perf3.log
-timeout 300 python tools/nn_perf4.py > gpurun_out/${TAG}_nn_perf4.log 2>&1; grep batch gpurun_out/${TAG}_nn_perf4.log
-for b in 40 80; do echo "== conv_lab_plain B=$b"; timeout 120 tools/ubench/conv_lab_plain $b 3 > gpurun_out/${TAG}_conv_lab_B$b.log 2>&1; cut -c1-44 gpurun_out/${TAG}_conv_lab_B$b.log; done
-timeout 900 python -m pytest tests -m gpu -q > gpurun_out/${TAG}_pytest_gpu.log 2>&1; grep -E "passed|failed" gpurun_out/${TAG}_pytest_gpu.log | tail -2
+# Round-2 check run: GPU parity suite (incl. the full-size configurations and the f16 range guard) and the three bench configurations
+TAG=${1:-r02e}
+timeout 1500 python -m pytest tests -m gpu -q -s > gpurun_out/${TAG}_pytest_gpu.log 2>&1; grep -E "passed|failed" gpurun_out/${TAG}_pytest_gpu.log | tail -2; grep -E "differing voxels|forward mismatches|out-of-f16|oracle pre" gpurun_out/${TAG}_pytest_gpu.log
+for c in 2 3 4; do timeout 300 python bench.py --config $c 2>gpurun_out/${TAG}_bench_c${c}_err.log | tail -1 > gpurun_out/${TAG}_bench_c$c.json; python - <<PY
+import json
+d=json.load(open("gpurun_out/${TAG}_bench_c$c.json"))
+print("config $c:", d["value"], d["ms_per_step"], "host:", d.get("value_host_to_host"))
+PY
+done
