@@ -1,6 +1,7 @@
 // extern "C" surface of liblungmask_hip.so (include/lungmask_hip.h).
 #include "engine.h"
 #ifndef LM_EMU_BUILD
+#include <chrono>
 #include <thread>
 #endif
 #include "post_kernels.h"
@@ -350,6 +351,10 @@ int lm_apply_host(lm_engine* e, int slot, int fill_slot, const void* vol_host, i
             return LM_ERR_DEVICE;
         }
     }
+    static const bool timing = [] { const char* v = getenv("LM_HOST_TIMING"); return v && v[0] == '1'; }();  // stderr breakdown of this call
+    const auto t_start = std::chrono::steady_clock::now();
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+    double t_tail = 0, t_touch = 0;
     e->tail_enqueued.store(0, std::memory_order_release);
     std::thread helper([&] {
         hipError_t terr = hipSuccess;
@@ -362,11 +367,14 @@ int lm_apply_host(lm_engine* e, int slot, int fill_slot, const void* vol_host, i
             if (terr == hipSuccess) terr = hipEventRecord(e->tail_ready, e->copy_stream);
         }
         e->tail_enqueued.store(terr == hipSuccess ? 1 : -1, std::memory_order_release);
+        t_tail = ms_since(t_start);
         volatile uint8_t* o = out_host;
         for (size_t i = 0; i < nvox; i += 4096) o[i] = 0;
         if (nvox) o[nvox - 1] = 0;
+        t_touch = ms_since(t_start);
     });
     hipError_t err = hipMemcpyAsync(e->app.vol.p, vol_host, (size_t)std::min(n, head) * slice * esz, hipMemcpyHostToDevice, e->stream);
+    const double t_head = ms_since(t_start);
     int rc = LM_OK;
     if (err != hipSuccess) {
         set_error("lm_apply_host: host-to-device copy failed: %s", hipGetErrorString(err));
@@ -376,14 +384,21 @@ int lm_apply_host(lm_engine* e, int slot, int fill_slot, const void* vol_host, i
         rc = apply_volume(e, slot, fill_slot, e->app.vol.p, dtype, n, h, w, batch_size, volume_postprocessing, e->app.out.as<uint8_t>());
         e->head_slices = 0;
     }
+    const double t_apply = ms_since(t_start);
     helper.join();
     if (rc != LM_OK) return rc;
+    const double t_join = ms_since(t_start);
 #else
     LM_HIP(hipMemcpyAsync(e->app.vol.p, vol_host, nvox * esz, hipMemcpyHostToDevice, e->stream));
     LM_TRY(apply_volume(e, slot, fill_slot, e->app.vol.p, dtype, n, h, w, batch_size, volume_postprocessing, e->app.out.as<uint8_t>()));
 #endif
     LM_HIP(hipMemcpyAsync(out_host, e->app.out.p, nvox, hipMemcpyDeviceToHost, e->stream));
     LM_HIP(hipStreamSynchronize(e->stream));
+#ifndef LM_EMU_BUILD
+    if (timing)
+        fprintf(stderr, "lm_apply_host: head H2D returned %.2f ms | helper: tail enqueued %.2f, pages touched %.2f | hot path returned %.2f | joined %.2f | D2H done %.2f ms\n", t_head,
+                t_tail, t_touch, t_apply, t_join, ms_since(t_start));
+#endif
     return LM_OK;
 }
 

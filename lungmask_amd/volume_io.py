@@ -542,7 +542,17 @@ def read_dicoms(path: str, primary: bool = True, original: bool = True) -> List[
         items = [i for i in infos if i[1] == sid]
         order = np.argsort(np.asarray([i[3][2] for i in items]), kind="stable")  # utils.py:208-211: by z position
         files = [items[k][2] for k in order]
-        vols.append(_read_series(files))
+        try:
+            vols.append(_read_series(files))
+        except DicomError as ex:
+            # e.g. a JPEG-lossless series: the header scan above accepts it, the pixel decoder is the reference's (ITK/GDCM),
+            # on the sorted file list -- as utils.py:213-220 reads every series
+            logger.info(f"built-in DICOM reader declined the series ({ex}); trying SimpleITK")
+            import SimpleITK as sitk
+
+            reader = sitk.ImageSeriesReader()
+            reader.SetFileNames(files)
+            vols.append(_sitk_to_volume(reader.Execute()))
     return vols
 
 

@@ -1,9 +1,10 @@
-# Round-2 check run: GPU parity suite (incl. the full-size configurations and the f16 range guard) and the three bench configurations
-TAG=${1:-r02e}
-timeout 1500 python -m pytest tests -m gpu -q -s > gpurun_out/${TAG}_pytest_gpu.log 2>&1; grep -E "passed|failed" gpurun_out/${TAG}_pytest_gpu.log | tail -2; grep -E "differing voxels|forward mismatches|out-of-f16|oracle pre" gpurun_out/${TAG}_pytest_gpu.log
-for c in 2 3 4; do timeout 300 python bench.py --config $c 2>gpurun_out/${TAG}_bench_c${c}_err.log | tail -1 > gpurun_out/${TAG}_bench_c$c.json; python - <<PY
+# Round-2 check run: distributed-path tests on the GPU (stream-ordered collectives, 2 ranks on 1 GPU), host boundary timing
+TAG=${1:-r02f}
+timeout 900 python -m pytest tests/test_gpu_apply.py -m gpu -q -s -k "rccl or sharded or lminferer or cli or force_cpu" > gpurun_out/${TAG}_pytest_dist.log 2>&1; grep -E "passed|failed|SKIP|skipped" gpurun_out/${TAG}_pytest_dist.log | tail -3; grep -i "RCCL2\|refuses" gpurun_out/${TAG}_pytest_dist.log | head -5
+timeout 300 python -m pytest tests/test_gpu_apply.py -m gpu -q -rs -k "two_ranks" 2>&1 | tail -5
+timeout 300 python bench.py --no-cpu-baseline 2>gpurun_out/${TAG}_bench_err.log | tail -1 > gpurun_out/${TAG}_bench.json; python - <<PY
 import json
-d=json.load(open("gpurun_out/${TAG}_bench_c$c.json"))
-print("config $c:", d["value"], d["ms_per_step"], "host:", d.get("value_host_to_host"))
+d=json.load(open("gpurun_out/${TAG}_bench.json"))
+print("config 2:", d["value"], d["ms_per_step"], "host:", d.get("value_host_to_host"))
 PY
-done
+LM_BENCH_FORCE_DIST=1 timeout 300 python bench.py --steps 3 --no-cpu-baseline 2>gpurun_out/${TAG}_bench_dist_err.log | tail -1 > gpurun_out/${TAG}_bench_forced_dist.json; cut -c1-200 gpurun_out/${TAG}_bench_forced_dist.json
