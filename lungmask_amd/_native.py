@@ -62,9 +62,11 @@ class Library:
         L.lm_copy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.lm_model_load.argtypes = [C.c_void_p, C.c_int, C.POINTER(_Tensor), C.c_int]
         L.lm_model_classes.argtypes = [C.c_void_p, C.c_int]
-        L.lm_engine_stream.argtypes = [C.c_void_p]
-        L.lm_engine_stream.restype = C.c_void_p
-        L.lm_model_precision.argtypes = [C.c_void_p, C.c_int]
+        if hasattr(L, "lm_engine_stream"):
+            L.lm_engine_stream.argtypes = [C.c_void_p]
+            L.lm_engine_stream.restype = C.c_void_p
+        if hasattr(L, "lm_model_precision"):  # (absent from older builds that tools/ab_forward.py may load for comparison)
+            L.lm_model_precision.argtypes = [C.c_void_p, C.c_int]
         L.lm_forward_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.lm_set_precision.argtypes = [C.c_void_p, C.c_int]
         L.lm_set_streams.argtypes = [C.c_void_p, C.c_int]

@@ -45,6 +45,13 @@ struct ConvLayer {
     char* w_h3 = nullptr;  // split-f16 packing [taps][Cout][Cin/8][hi8|lo8] of w * 2^k
     float h3_acc_scale = 1.f;  // 2^-k
     int cin = 0, cout = 0, taps = 0;
+    // Deferred BatchNorm shift of the split-f16 path (nn_engine.hip, "r-form"): a Conv->ReLU->BN layer stores r = relu(.)*s and
+    // leaves its shift t to the consumers -- half of r is exactly zero, and zero operands cost the matrix pipes less power.
+    // For THIS layer as a consumer of a tensor with per-channel shift T: bias_h3 = bias + sum_taps S[tap], S[tap][co] =
+    // sum_ci w[co][ci][tap] T[ci]; corr_h3[mask][co] = sum over the taps that fall outside the image for border mask
+    // (1 top, 2 bottom, 4 left, 8 right) of S[tap][co] (zero padding pads the TRUE activation, not r).
+    float *bias_h3 = nullptr, *corr_h3 = nullptr;
+    std::vector<float> h_bn_t;  // host copy of this layer's own shift (empty: no BatchNorm)
 };
 
 struct Model {
@@ -55,6 +62,8 @@ struct Model {
     ConvLayer up1x1[4];    // up_path.i.up.1
     ConvLayer upc[4][2];   // up_path.i.conv_block.block.{0,3}
     float *head_w = nullptr, *head_b = nullptr;
+    float* head_b_h3 = nullptr;  // head bias + head_w . (shift of the last conv): the head reads an r-form tensor
+    float* zeros_h3 = nullptr;   // 1024 zeros: the "shift" a deferred-shift producer applies
     std::vector<void*> allocs;
     // The split-f16 path stores activations as f16 pairs: a model whose activations left the f16 range (detected by the
     // kernels' range guard) is pinned to the exact-fp32 kernels from then on.

@@ -225,6 +225,27 @@ __device__ __forceinline__ void lm_split4(float v0, float v1, float v2, float v3
     lo->x = lm_round_lo_pair(lo->x);
     lo->y = lm_round_lo_pair(lo->y);
 }
+// f16 range guard on the hi halves themselves: running maximum of |hi| as bit patterns, two halves per register (one AND + one
+// packed max per 4 values in the epilogue instead of a float max per value).  |hi| >= 0x7800 (32768.0) also catches inf / NaN.
+__device__ __forceinline__ unsigned lm_pk_absmax_u16(unsigned acc, unsigned two_halves) {
+    const unsigned m = two_halves & 0x7fff7fffu;
+#ifdef LM_EMU_BUILD
+    const unsigned lo = (acc & 0xffffu) > (m & 0xffffu) ? (acc & 0xffffu) : (m & 0xffffu);
+    const unsigned hi = (acc >> 16) > (m >> 16) ? (acc >> 16) : (m >> 16);
+    return lo | (hi << 16);
+#else
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    u16x2 a, b;
+    __builtin_memcpy(&a, &acc, 4);
+    __builtin_memcpy(&b, &m, 4);
+    a = __builtin_elementwise_max(a, b);  // v_pk_max_u16
+    unsigned r;
+    __builtin_memcpy(&r, &a, 4);
+    return r;
+#endif
+}
+__device__ __forceinline__ bool lm_pk_out_of_f16_guard(unsigned acc) { return (acc & 0xffffu) >= 0x7800u || (acc >> 16) >= 0x7800u; }
+
 // one value (the first conv writes single channels)
 __device__ __forceinline__ lm_h16 lm_round_lo1(lm_h16 l) {
     unsigned short u;

@@ -190,10 +190,42 @@ float f16_to_f32(uint16_t h) {
 // conv weight [cout][cin][kh][kw] -> [tap = kh*3+kw][cin][cout]; optional BatchNorm (eval) folded to
 // the per-channel affine y = x*s + t, s = gamma/sqrt(var+1e-5), t = beta - mean*s (applied AFTER ReLU,
 // resunet.py:97-100 -- it cannot be folded into the conv).
-int load_conv(Model& md, const TensorMap& tm, const std::string& conv, const std::string& bnp, int cin, int cout, int taps, ConvLayer* L) {
+// t_in: the per-channel shift T carried by this layer's INPUT tensor in the split-f16 path's deferred-shift form (nullptr:
+// none) -- see ConvLayer::bias_h3.
+int load_conv(Model& md, const TensorMap& tm, const std::string& conv, const std::string& bnp, int cin, int cout, int taps, ConvLayer* L,
+              const std::vector<float>* t_in = nullptr) {
     const lm_tensor* w = tm.get(conv + ".weight", (int64_t)cout * cin * taps);
     const lm_tensor* b = tm.get(conv + ".bias", cout);
     if (!w || !b) return LM_ERR_INVALID;
+    {
+        // S[tap][co] = sum_ci w[co][ci][tap] * T[ci] in double; bias_h3 = bias + all taps; corr_h3[mask] = the taps that the
+        // border mask (1 top, 2 bottom, 4 left, 8 right) puts outside the image
+        std::vector<double> S((size_t)taps * cout, 0.0);
+        if (t_in != nullptr && (int)t_in->size() == cin)
+            for (int o = 0; o < cout; ++o)
+                for (int i = 0; i < cin; ++i) {
+                    const double ti = (*t_in)[i];
+                    if (ti == 0.0) continue;
+                    for (int t = 0; t < taps; ++t) S[(size_t)t * cout + o] += (double)w->data[((size_t)o * cin + i) * taps + t] * ti;
+                }
+        std::vector<float> be(cout), corr((size_t)16 * cout, 0.f);
+        for (int o = 0; o < cout; ++o) {
+            double full = 0;
+            for (int t = 0; t < taps; ++t) full += S[(size_t)t * cout + o];
+            be[o] = (float)((double)b->data[o] + full);
+            if (taps == 9)
+                for (int mask = 1; mask < 16; ++mask) {
+                    double c = 0;
+                    for (int t = 0; t < 9; ++t) {
+                        const int dy = t / 3, dx = t % 3;
+                        if (((mask & 1) && dy == 0) || ((mask & 2) && dy == 2) || ((mask & 4) && dx == 0) || ((mask & 8) && dx == 2)) c += S[(size_t)t * cout + o];
+                    }
+                    corr[(size_t)mask * cout + o] = (float)c;
+                }
+        }
+        LM_TRY(upload(md, be, &L->bias_h3));
+        if (taps == 9 && t_in != nullptr) LM_TRY(upload(md, corr, &L->corr_h3));
+    }
     std::vector<float> pw((size_t)taps * cin * cout);
     for (int o = 0; o < cout; ++o)
         for (int i = 0; i < cin; ++i)
@@ -244,6 +276,7 @@ int load_conv(Model& md, const TensorMap& tm, const std::string& conv, const std
         }
         LM_TRY(upload(md, s, &L->bn_s));
         LM_TRY(upload(md, t, &L->bn_t));
+        L->h_bn_t = t;
     }
     L->cin = cin;
     L->cout = cout;
@@ -274,6 +307,9 @@ int model_load(lm_engine* e, int slot, const lm_tensor* tensors, int n) {
         return LM_ERR_INVALID;
     }
     md.n_classes = C;
+    // (the shift each layer's input tensor carries in the deferred-shift form of the split-f16 path is the BatchNorm shift of
+    // the layer that produced it -- pooling and the bilinear upsample pass a per-channel constant through unchanged; the 1x1
+    // convs have no BatchNorm and emit true values)
     int prev = 1;
     for (int i = 0; i < 5; ++i) {
         const int co = 64 << i;
@@ -281,22 +317,34 @@ int model_load(lm_engine* e, int slot, const lm_tensor* tensors, int n) {
         if (i == 0)
             LM_TRY(load_conv(md, tm, p + "0", p + "2", 1, co, 9, &md.first));
         else
-            LM_TRY(load_conv(md, tm, p + "0", p + "2", prev, co, 9, &md.down[i][0]));
-        LM_TRY(load_conv(md, tm, p + "3", p + "5", co, co, 9, &md.down[i][1]));
+            LM_TRY(load_conv(md, tm, p + "0", p + "2", prev, co, 9, &md.down[i][0], &md.down[i - 1][1].h_bn_t));  // pooled skip tensor
+        LM_TRY(load_conv(md, tm, p + "3", p + "5", co, co, 9, &md.down[i][1], i == 0 ? &md.first.h_bn_t : &md.down[i][0].h_bn_t));
         prev = co;
     }
     for (int i = 0; i < 4; ++i) {
         const int co = 512 >> i;
         const std::string p = "up_path." + std::to_string(i);
-        LM_TRY(load_conv(md, tm, p + ".up.1", "", prev, co, 1, &md.up1x1[i]));
-        LM_TRY(load_conv(md, tm, p + ".conv_block.block.0", p + ".conv_block.block.2", prev, co, 9, &md.upc[i][0]));
-        LM_TRY(load_conv(md, tm, p + ".conv_block.block.3", p + ".conv_block.block.5", co, co, 9, &md.upc[i][1]));
+        LM_TRY(load_conv(md, tm, p + ".up.1", "", prev, co, 1, &md.up1x1[i], i == 0 ? &md.down[4][1].h_bn_t : &md.upc[i - 1][1].h_bn_t));
+        std::vector<float> t_cat(2 * (size_t)co, 0.f);  // torch.cat([up, bridge], 1) (resunet.py:147): the up half is exact, the skip half shifted
+        std::copy(md.down[3 - i][1].h_bn_t.begin(), md.down[3 - i][1].h_bn_t.end(), t_cat.begin() + co);
+        LM_TRY(load_conv(md, tm, p + ".conv_block.block.0", p + ".conv_block.block.2", prev, co, 9, &md.upc[i][0], &t_cat));
+        LM_TRY(load_conv(md, tm, p + ".conv_block.block.3", p + ".conv_block.block.5", co, co, 9, &md.upc[i][1], &md.upc[i][0].h_bn_t));
         prev = co;
     }
     const lm_tensor* hw = tm.get("last.weight", (int64_t)C * 64);
     if (!hw) return LM_ERR_INVALID;
     LM_TRY(upload(md, std::vector<float>(hw->data, hw->data + C * 64), &md.head_w));
     LM_TRY(upload(md, std::vector<float>(it->second->data, it->second->data + C), &md.head_b));
+    {
+        std::vector<float> hb(C);
+        for (int c = 0; c < C; ++c) {
+            double a = it->second->data[c];
+            for (int k = 0; k < 64; ++k) a += (double)hw->data[c * 64 + k] * (double)md.upc[3][1].h_bn_t[k];
+            hb[c] = (float)a;
+        }
+        LM_TRY(upload(md, hb, &md.head_b_h3));
+        LM_TRY(upload(md, std::vector<float>(1024, 0.f), &md.zeros_h3));
+    }
     md.loaded = true;
     return LM_OK;
 }
@@ -310,6 +358,8 @@ struct Fwd {
     int B;
     int kc3, kc1, kfirst, kup, khead;
     bool h3;  // split-f16 kernels (else the exact-fp32 ones)
+    bool defer = false;            // split-f16 only: BatchNorm shifts deferred to the consumers (ConvLayer::bias_h3)
+    const float* zeros = nullptr;  // Model::zeros_h3
 
     bool head_fused = false;  // set by conv() when the head ran inside the last conv's epilogue
 
@@ -352,9 +402,10 @@ struct Fwd {
             q.in_coff = in_co;
             q.w = L.w_h3;
             q.acc_scale = L.h3_acc_scale;
-            q.bias = L.bias;
+            q.bias = defer ? L.bias_h3 : L.bias;
             q.bn_s = L.bn_s;
-            q.bn_t = L.bn_t;
+            q.bn_t = (defer && L.bn_t) ? zeros : L.bn_t;  // deferred shift: the consumers add it (ConvLayer::bias_h3)
+            q.border_corr = defer ? L.corr_h3 : nullptr;
             q.out = reinterpret_cast<char*>(out);
             q.out_cstride = out_cs;
             q.out_coff = out_co;
@@ -414,6 +465,10 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
     const bool h3 = e->precision == 1 && !md.force_f32;
     Fwd f{e, stream, B, e->prof.kind_id(h3 ? "conv3x3_igemm_h3" : "conv3x3_igemm_f32"), e->prof.kind_id(h3 ? "conv1x1_igemm_h3" : "conv1x1_igemm_f32"),
           e->prof.kind_id("first_conv"), e->prof.kind_id("upsample2x"), e->prof.kind_id("head_argmax"), h3};
+    // LM_H3_DEFER_SHIFT=0: A/B hook (the tensors then hold the true activations, as in the exact-fp32 path)
+    static const bool defer_ok = [] { const char* v = getenv("LM_H3_DEFER_SHIFT"); return !(v && v[0] == '0'); }();
+    f.defer = h3 && defer_ok;
+    f.zeros = md.zeros_h3;
     if (h3 && !e->zero_page) {
         void* zp = nullptr;
         LM_HIP(hipMalloc(&zp, 512));
@@ -428,7 +483,7 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
 
     // ---- encoder (resunet.py:60-64)
     {
-        FirstConvParams p{x, md.first.w, md.first.bias, md.first.bn_s, md.first.bn_t, t1, 64, 0, B, H, W, h3 ? e->range_flag : nullptr};
+        FirstConvParams p{x, md.first.w, md.first.bias, md.first.bn_s, f.defer ? md.zeros_h3 : md.first.bn_t, t1, 64, 0, B, H, W, h3 ? e->range_flag : nullptr};
         e->prof.begin(stream, f.kfirst, 2.0 * px * 64 * 9, 4.0 * px * 65);
         hipError_t err = h3 ? launch_first_conv_h3(p, stream) : launch_first_conv(p, stream);
         e->prof.end(stream);
@@ -464,12 +519,12 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
         }
         LM_TRY(f.conv(md.upc[i][0], ws.cat[lvl].as<float>(), 2 * c, 0, h, w, t1, c, 0));
         // the last conv takes the head (1x1 conv + argmax) into its epilogue when only labels are wanted
-        const HeadParams hp{t3, md.head_w, md.head_b, labels, logp, B, H, W, md.n_classes};
+        const HeadParams hp{t3, md.head_w, f.defer ? md.head_b_h3 : md.head_b, labels, logp, B, H, W, md.n_classes};
         LM_TRY(f.conv(md.upc[i][1], t1, c, 0, h, w, t3, c, 0, nullptr, 0, 0, i == 3 ? &hp : nullptr));
     }
     // ---- head (resunet.py:69-70, mask.py:184-186)
     if (!f.head_fused) {
-        HeadParams p{t3, md.head_w, md.head_b, labels, logp, B, H, W, md.n_classes};
+        HeadParams p{t3, md.head_w, f.defer ? md.head_b_h3 : md.head_b, labels, logp, B, H, W, md.n_classes};
         e->prof.begin(stream, f.khead, 2.0 * px * 64 * md.n_classes, 4.0 * px * 64 + px);
         hipError_t err = h3 ? launch_head_h3(p, stream) : launch_head(p, stream);
         e->prof.end(stream);

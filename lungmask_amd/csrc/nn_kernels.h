@@ -74,6 +74,10 @@ struct ConvParamsH3 {
     const float* head_b = nullptr;   // [C]
     uint8_t* head_labels = nullptr;  // [B][H][W]
     int head_C = 0;
+    // Border correction of a consumer of a deferred-shift ("r-form") tensor: [16][Cout] floats indexed by the pixel's border mask
+    // (1 top row, 2 bottom row, 4 left column, 8 right column), SUBTRACTED from the bias for pixels on the image border; the
+    // interior part is folded into `bias` by the host.  nullptr: the input tensor carries no shift.  3x3 only.
+    const float* border_corr = nullptr;
     // f16 range guard: hi = f16(v) overflows beyond 65504 and nothing downstream would notice.  Every producer of a split
     // tensor ORs 1 into this device word when a value it writes is not below kF16Guard in magnitude (or is not finite);
     // the engine checks the word after the forward and re-runs the model on the exact-fp32 kernels (nn_engine.hip).

@@ -165,7 +165,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h3(ConvParamsH3 p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cb = n0 + 32 * mt + 8 * g + 4 * kb;  // first of 4 consecutive output channels
-                const float4 bias = *reinterpret_cast<const float4*>(p.bias + cb);
+                float4 bias = *reinterpret_cast<const float4*>(p.bias + cb);
+                if (TAPS == 9 && p.border_corr != nullptr) {  // deferred-shift input: taps outside the image saw 0, not -T
+                    const int mask = (y == 0 ? 1 : 0) | (y == p.H - 1 ? 2 : 0) | (x == 0 ? 4 : 0) | (x == p.W - 1 ? 8 : 0);
+                    const float4 c = *reinterpret_cast<const float4*>(p.border_corr + (size_t)mask * p.Cout + cb);
+                    bias.x -= c.x;
+                    bias.y -= c.y;
+                    bias.z -= c.z;
+                    bias.w -= c.w;
+                }
                 float v[4];
                 v[0] = fmaf(accm[mt][nt][4 * g + 0], p.acc_scale, bias.x);
                 v[1] = fmaf(accm[mt][nt][4 * g + 1], p.acc_scale, bias.y);
@@ -325,7 +333,9 @@ __device__ __forceinline__ float4 as_float4(const lm_h16x8& v) {
         H3P_STEP(FB, FA, AS, 2, 2);          \
     } while (0)
 
-template <int TAPS, bool G16>
+// HEAD: the fused-head form of the epilogue (last decoder conv, labels only) -- a separate instantiation, so that the 16 other
+// launches of a forward do not carry its registers.
+template <int TAPS, bool G16, bool HEAD = false>
 __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptiles, int n_items, int xcd_order) {
     using SM = H3WSmem<TAPS, G16>;
     constexpr int HALO = SM::HALO, PW = SM::PW, TWW = SM::TWW, NW = SM::NW, ROWB = PW * 64, NTSTEP = SM::NTSTEP;
@@ -341,7 +351,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
     constexpr int STAGE_EXTRA = STAGE_BYTES <= SM::BUF_BYTES ? 0 : STAGE_BYTES;
     __shared__ __attribute__((aligned(1024))) char lds[2 * SM::BUF_BYTES + STAGE_EXTRA];
     __shared__ __attribute__((aligned(16))) float epi[2][3][TN];  // bias, bn scale, bn shift of the item (double buffered)
-    __shared__ __attribute__((aligned(16))) float hw[(TAPS == 9 && !G16) ? kMaxClasses * 64 + kMaxClasses : 4];  // fused head: weights, bias
+    __shared__ __attribute__((aligned(16))) float hw[HEAD ? kMaxClasses * 64 + kMaxClasses : 4];  // fused head: weights, bias
 
     const int tid = threadIdx.x, lane = tid & 63, wave = lm_uniform(tid >> 6);
     const int li = lane & 31, kb = lane >> 5;
@@ -362,8 +372,8 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
     const int w_off_lo = w_off ^ 16;
 
     // ---- DMA lane geometry (item invariant): which halo pixel / weight row this lane feeds
-    unsigned relA[SM::A_PER_WAVE];
-    int pyx[SM::A_PER_WAVE];  // py | px << 8 | slice << 16, or -1 when the lane has nothing to do for that piece
+    unsigned relA[SM::A_PER_WAVE];  // source offset of this lane's 16 bytes relative to the halo tile's top-left pixel
+    int pyx[SM::A_PER_WAVE];        // py | px << 8 | slice << 16, or -1 when the lane has nothing to do for that piece
 #pragma unroll
     for (int j = 0; j < SM::A_PER_WAVE; ++j) {
         const int piece = wave + NW * j, idx = piece * 64 + lane;
@@ -373,7 +383,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
             const int row = idx >> 2;
             const int sl = row / SM::SL_ROWS, rr = row - sl * SM::SL_ROWS;
             const int py = rr / PW, px = rr - py * PW;
-            const int ls = (idx & 3) ^ ((px >> ASWZ) & 3);
+            const int ls = (idx & 3) ^ ((px >> ASWZ) & 3);  // logical 16-byte slot behind this lane's physical one
             relA[j] = (unsigned)(((sl * p.H + py) * p.W + px) * p.in_cstride * 4 + (ls >> 1) * 32 + (ls & 1) * 16);
             pyx[j] = py | (px << 8) | (sl << 16);
         }
@@ -401,22 +411,25 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
     //     workgroups that run together on one XCD work on a few pixel tiles x ALL cout tiles, so an activation tile is
     //     fetched once and hit in that XCD's L2 by the other cout tiles.  Returns false for the padding of the last row.
     const int n_ct = p.Cout / TN;
+    const int tiles_y = (p.H + TH - 1) / TH;
+    // every tile count of this network is a power of two: shifts instead of integer divisions on the item-switch path
+    const bool pow2 = ((n_ct & (n_ct - 1)) | (tiles_x & (tiles_x - 1)) | (tiles_y & (tiles_y - 1))) == 0;
+    const int sh_ct = 31 - __clz(n_ct), sh_tx = 31 - __clz(tiles_x), sh_ty = 31 - __clz(tiles_y);
     auto decode = [&](int it, int& b, int& y0, int& x0, int& n0) -> bool {
         int ct, pt;
         if (xcd_order) {
             const int x = it & 7, s = it >> 3;
-            ct = s % n_ct;
-            pt = (s / n_ct) * 8 + x;
+            ct = pow2 ? (s & (n_ct - 1)) : s % n_ct;
+            pt = (pow2 ? (s >> sh_ct) : s / n_ct) * 8 + x;
         } else {
             ct = it / n_ptiles;
             pt = it - ct * n_ptiles;
         }
         const bool valid = pt < n_ptiles;
-        const int tx = pt % tiles_x;
-        pt /= tiles_x;
-        const int tiles_y = (p.H + TH - 1) / TH;
-        const int ty = pt % tiles_y;
-        b = (pt / tiles_y) * SM::NSL;  // first slice of the item
+        const int tx = pow2 ? (pt & (tiles_x - 1)) : pt % tiles_x;
+        pt = pow2 ? (pt >> sh_tx) : pt / tiles_x;
+        const int ty = pow2 ? (pt & (tiles_y - 1)) : pt % tiles_y;
+        b = (pow2 ? (pt >> sh_ty) : pt / tiles_y) * SM::NSL;  // first slice of the item
         y0 = ty * TH;
         x0 = tx * TWW;
         n0 = ct * TN;
@@ -433,14 +446,14 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
         }
     };
 
+    unsigned voffC[SM::A_PER_WAVE], voffN[SM::A_PER_WAVE];  // this item's / the next item's source offsets
     // ---- the pending stage: the chunk whose DMA pieces the slots of the running taps issue
-    unsigned d_voff[SM::A_PER_WAVE];
+    bool d_next = false;  // the stage belongs to the NEXT item (its source offsets are voffN)
     unsigned d_soffA = 0, d_soffW = 0;
     char* d_buf = lds;
     int d_nA = 0, d_nW = 0, d_epi = -1, d_n0 = 0;  // piece counts (0: nothing to stage); epi buffer to fill or -1
-    auto set_dma = [&](const unsigned* voff, int b, int n0, int c0, int par, bool on, int epar_or_neg) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < SM::A_PER_WAVE; ++j) d_voff[j] = voff[j];
+    auto set_dma = [&](bool next_item, int b, int n0, int c0, int par, bool on, int epar_or_neg) __attribute__((always_inline)) {
+        d_next = next_item;
         d_soffA = (unsigned)b * slice_bytes + (unsigned)c0 * 4u;
         d_soffW = ((unsigned)n0 * (unsigned)p.Cin + (unsigned)c0) * 4u;
         d_buf = lds + par * SM::BUF_BYTES;
@@ -461,7 +474,10 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
         if (k == N_SLOTS - 1) {
             if (d_epi >= 0 && wave < (bn ? 3 : 1)) lm_dma4_global(epi_src + d_n0, &epi[d_epi][wave][0]);
         } else if ((k & 1) == 0) {
-            if (j < SM::A_PER_WAVE && wave + NW * j < d_nA) lm_dma16(rsrcA, d_voff[j < SM::A_PER_WAVE ? j : 0], d_soffA, d_buf + (wave + NW * j) * 1024);
+            if (j < SM::A_PER_WAVE && wave + NW * j < d_nA) {
+                const int jj = j < SM::A_PER_WAVE ? j : 0;
+                lm_dma16(rsrcA, d_next ? voffN[jj] : voffC[jj], d_soffA, d_buf + (wave + NW * j) * 1024);
+            }
         } else {
             if (j < SM::W_PER_WAVE && wave + NW * j < d_nW)
                 lm_dma16(rsrcW, voffW, d_soffW + (unsigned)j * w_piece_stride, d_buf + SM::A_BYTES + (wave + NW * j) * 1024);
@@ -477,18 +493,17 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
         epi[0][1 + tid / TN][tid % TN] = tid < TN ? 1.f : 0.f;
         epi[1][1 + tid / TN][tid % TN] = tid < TN ? 1.f : 0.f;
     }
-    const bool fuse_head = TAPS == 9 && !G16 && p.head_labels != nullptr;
-    if (TAPS == 9 && !G16 && fuse_head) {
+    static_assert(!HEAD || (TAPS == 9 && !G16), "the fused head belongs to the 32-wide 3x3 form");
+    if constexpr (HEAD) {
         for (int i = tid; i < p.head_C * 64; i += 512) hw[i] = p.head_w[i];
         if (tid < p.head_C) hw[kMaxClasses * 64 + tid] = p.head_b[tid];
     }
-    unsigned voffC[SM::A_PER_WAVE], voffN[SM::A_PER_WAVE];  // this item's / the next item's source offsets
     item_voffs(b, y0, x0, voffC);
     int epar = 0;
     char* const buf0 = lds;
     char* const buf1 = lds + SM::BUF_BYTES;
     // prologue: chunk 0 of the first item, all pieces at once
-    set_dma(voffC, b, n0, 0, 0, true, epar);
+    set_dma(false, b, n0, 0, 0, true, epar);
 #pragma unroll
     for (int k = 0; k < N_SLOTS; ++k) dma_slot(k);
     lm_barrier_dma();
@@ -511,7 +526,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
         lm_h16x8 f[8], g[8];  // two fragment sets: whi0 whi1 wlo0 wlo1 a0hi a0lo a1hi a1lo
         bool abl_r = false;   // lab ablation (constant false in the product)
         if constexpr (TAPS == 9) {
-            set_dma(voffC, b, n0, KC, 1, true, -1);  // chunk 1 -> buffer 1, issued from the slots of chunk 0
+            set_dma(false, b, n0, KC, 1, true, -1);  // chunk 1 -> buffer 1, issued from the slots of chunk 0
             H3P_READS(f, buf0, 0, 0);
             for (int ci = 0; ci < nchunks; ci += 2) {
                 abl_r = LM_ABL_READS(ci);
@@ -522,8 +537,8 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                 lm_barrier_dma();  // everyone has read buffer 0 for the last time; chunk ci + 1 is complete in buffer 1
                 LM_TRACE_MARK(1);
                 H3P_READS(g, buf1, 0, 0);
-                if (ci + 2 < nchunks) set_dma(voffC, b, n0, (ci + 2) * KC, 0, true, -1);
-                else set_dma(voffN, nb, nn0, 0, 0, have_next, epar ^ 1);  // the next item's chunk 0 + epilogue constants
+                if (ci + 2 < nchunks) set_dma(false, b, n0, (ci + 2) * KC, 0, true, -1);
+                else set_dma(true, nb, nn0, 0, 0, have_next, epar ^ 1);  // the next item's chunk 0 + epilogue constants
                 H3P_MFMAS(f);
                 // ---- odd chunk ci + 1 (buffer 1), fragments start in g
                 H3P_CHUNK_STEPS(g, f, buf1);
@@ -533,9 +548,9 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                 LM_TRACE_MARK(1);
                 if (ci + 2 < nchunks) {
                     H3P_READS(f, buf0, 0, 0);
-                    set_dma(voffC, b, n0, (ci + 3) * KC, 1, true, -1);
+                    set_dma(false, b, n0, (ci + 3) * KC, 1, true, -1);
                 } else {
-                    set_dma(voffC, b, n0, 0, 1, false, -1);  // buffer 1 becomes the epilogue's staging area
+                    set_dma(false, b, n0, 0, 1, false, -1);  // buffer 1 becomes the epilogue's staging area
                 }
                 H3P_MFMAS(g);
             }
@@ -543,8 +558,8 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
             for (int ci = 0; ci < nchunks; ++ci) {
                 // chunk ci is resident in buffer ci & 1; stage the next one (or the next item's first) into the other
                 const char* as = (ci & 1) ? buf1 : buf0;
-                if (ci + 1 < nchunks) set_dma(voffC, b, n0, (ci + 1) * KC, (ci + 1) & 1, true, -1);
-                else set_dma(voffN, nb, nn0, 0, 0, have_next, epar ^ 1);
+                if (ci + 1 < nchunks) set_dma(false, b, n0, (ci + 1) * KC, (ci + 1) & 1, true, -1);
+                else set_dma(true, nb, nn0, 0, 0, have_next, epar ^ 1);
 #pragma unroll
                 for (int k = 0; k < N_SLOTS; ++k) dma_slot(k);
                 H3P_READS(f, as, 0, 0);
@@ -560,12 +575,12 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
             // accumulator layout (lane = pixel, 8 bytes per 4 couts: 64 scattered lines per store) into full
             // 256-byte pixel rows written 16 bytes per lane (the scattered form cost ~10 us per tile in the TA).
             char* stage = (STAGE_EXTRA ? lds + 2 * SM::BUF_BYTES : buf1) + wave * (32 * PSTR);
-            float amax = 0.f;  // largest magnitude this lane hands to the split (f16 range guard)
+            unsigned gmax = 0u;  // running max of the |hi| halves this lane writes (f16 range guard, lm_pk_absmax_u16)
             const int bs = b + wsl;                      // slice this wave writes
             const int yb = y0 + (G16 ? 4 * (wave & 3) : 2 * wave);  // first image row of the wave's N-tile 0
             const int Hp = p.H >> 1, Wp = p.W >> 1;
             const char* ep = reinterpret_cast<const char*>(&epi[epar][0][0]);
-            if (TAPS == 9 && !G16 && fuse_head) {
+            if constexpr (HEAD) {
                 // ---- fused head: this item holds ALL 64 channels of its pixels (n0 == 0).  Per pixel the two lanes kb = 0/1
                 // own channels 8q + 4kb + k (q = mg, k = 0..3).  launch_head_h3 sums each 8-channel block as one fma chain
                 // (k = 0..7 from 0) and then adds the blocks pairwise (q ^ 4, q ^ 2, q ^ 1): the chain is continued across
@@ -575,6 +590,8 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                 for (int nt = 0; nt < 2; ++nt) {
                     const int yl = yb + nt;
                     const bool tile_ok = bs < p.B && yl < p.H;
+                    const int bmask = (yl == 0 ? 1 : 0) | (yl == p.H - 1 ? 2 : 0) | (x0 + li == 0 ? 4 : 0) | (x0 + li == p.W - 1 ? 8 : 0);
+                    const bool border = p.border_corr != nullptr && __any(bmask != 0);  // wave-uniform
                     float vv[8][4];
 #pragma unroll
                     for (int mg = 0; mg < 8; ++mg) {
@@ -586,17 +603,25 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                         LM_LDS_READ128(e2, ep + cl * 4, 2 * TN * 4);
                         LM_LDS_WAIT3(0, e0, e1, e2);
                         const float4 bias = as_float4(e0), s = as_float4(e1), sh = as_float4(e2);
-                        const float bb[4] = {bias.x, bias.y, bias.z, bias.w}, ss[4] = {s.x, s.y, s.z, s.w}, tt[4] = {sh.x, sh.y, sh.z, sh.w};
+                        float bb[4] = {bias.x, bias.y, bias.z, bias.w};
+                        const float ss[4] = {s.x, s.y, s.z, s.w}, tt[4] = {sh.x, sh.y, sh.z, sh.w};
+                        if (border) {  // deferred-shift input: the taps outside the image saw 0, not -T (ConvParamsH3::border_corr)
+                            const float4 c = *reinterpret_cast<const float4*>(p.border_corr + (size_t)bmask * p.Cout + n0 + cl);
+                            bb[0] -= c.x;
+                            bb[1] -= c.y;
+                            bb[2] -= c.z;
+                            bb[3] -= c.w;
+                        }
                         float v[4];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             float t = fmaf(accm[mt][nt][4 * g4 + k], p.acc_scale, bb[k]);
                             if (bn) t = fmaf(fmaxf(t, 0.f), ss[k], tt[k]);
                             v[k] = t;
-                            amax = fmaxf(amax, fabsf(t));
                         }
                         uint2 ph, plo;
                         lm_split4(v[0], v[1], v[2], v[3], &ph, &plo);
+                        gmax = lm_pk_absmax_u16(lm_pk_absmax_u16(gmax, ph.x), ph.y);
                         lm_unsplit4(ph, plo, vv[mg]);
                     }
                     float best = 0.f;
@@ -634,6 +659,9 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                 // image row of this lane's pixel in N-tile nt, and whether the wave's 32 pixels of this N-tile exist
                 const int yl = G16 ? yb + 2 * nt + (li >> 4) : yb + nt;
                 const bool tile_ok = bs < p.B && (G16 ? yb + 2 * nt + 1 < p.H : yb + nt < p.H);
+                const int xl = G16 ? wcol : x0 + li;
+                const int bmask = (yl == 0 ? 1 : 0) | (yl == p.H - 1 ? 2 : 0) | (xl == 0 ? 4 : 0) | (xl == p.W - 1 ? 8 : 0);
+                const bool border = TAPS == 9 && p.border_corr != nullptr && __any(bmask != 0);  // wave-uniform
 #pragma unroll
                 for (int mg = 0; mg < 8; ++mg) {
                     const int mt = mg >> 2, g4 = mg & 3;
@@ -644,18 +672,26 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                     LM_LDS_READ128(e2, ep + cl * 4, 2 * TN * 4);
                     LM_LDS_WAIT3(0, e0, e1, e2);
                     const float4 bias = as_float4(e0), s = as_float4(e1), sh = as_float4(e2);
-                    const float bb[4] = {bias.x, bias.y, bias.z, bias.w}, ss[4] = {s.x, s.y, s.z, s.w}, tt[4] = {sh.x, sh.y, sh.z, sh.w};
+                    float bb[4] = {bias.x, bias.y, bias.z, bias.w};
+                    const float ss[4] = {s.x, s.y, s.z, s.w}, tt[4] = {sh.x, sh.y, sh.z, sh.w};
+                    if (border) {
+                        const float4 c = *reinterpret_cast<const float4*>(p.border_corr + (size_t)bmask * p.Cout + n0 + cl);
+                        bb[0] -= c.x;
+                        bb[1] -= c.y;
+                        bb[2] -= c.z;
+                        bb[3] -= c.w;
+                    }
                     float v[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         float t = fmaf(accm[mt][nt][4 * g4 + k], p.acc_scale, bb[k]);
                         if (bn) t = fmaf(fmaxf(t, 0.f), ss[k], tt[k]);
                         v[k] = t;
-                        amax = fmaxf(amax, fabsf(t));
                         if (!G16) pl[mg][k] = nt == 0 ? t : pl[mg][k] + t;
                     }
                     uint2 ph, plo;
                     lm_split4(v[0], v[1], v[2], v[3], &ph, &plo);
+                    gmax = lm_pk_absmax_u16(lm_pk_absmax_u16(gmax, ph.x), ph.y);
                     char* d = stage + li * PSTR + (cl >> 3) * 32 + (cl & 7) * 2;
                     *reinterpret_cast<uint2_a*>(d) = ph;
                     *reinterpret_cast<uint2_a*>(d + 16) = plo;
@@ -700,8 +736,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                 }
             }
             }  // stored-output epilogue
-            // fmaxf drops a NaN operand, but a NaN can only come from an infinity that an earlier producer has flagged
-            if (p.range_flag != nullptr && !(amax < kF16Guard)) atomicOr(p.range_flag, 1u);
+            if (p.range_flag != nullptr && lm_pk_out_of_f16_guard(gmax)) atomicOr(p.range_flag, 1u);
         }
         LM_TRACE_MARK(3);
         if (!have_next) break;
@@ -766,6 +801,8 @@ static hipError_t launch_conv_h3_t(const ConvParamsH3& p, hipStream_t stream) {
             const unsigned blocks = (unsigned)std::min(n_items, n_cu);
             if (g16)
                 LM_LAUNCH((conv_igemm_h3p<TAPS, true>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
+            else if (TAPS == 9 && pd.head_labels != nullptr)
+                LM_LAUNCH((conv_igemm_h3p<9, false, true>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
             else
                 LM_LAUNCH((conv_igemm_h3p<TAPS, false>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
             const hipError_t err = hipGetLastError();
@@ -818,23 +855,25 @@ __global__ __launch_bounds__(256) void first_conv_h3_kernel(FirstConvParams p) {
     for (int k = 0; k < 9; ++k) wr[k] = wsm[k * 64 + lane];
     const float bias = p.bias[lane], s = p.bn_s[lane], sh = p.bn_t[lane];
     char* out = reinterpret_cast<char*>(p.out);
-    float amax = 0.f;  // f16 range guard
+    unsigned gmax = 0u;  // f16 range guard (running max of |hi| bit patterns)
     for (int pix = 0; pix < 64; ++pix) {
         const int r = 4 * wave + (pix >> 4), c = pix & 15;
         float v = bias;
 #pragma unroll
         for (int k = 0; k < 9; ++k) v = fmaf(tile[(r + k / 3) * 18 + c + (k % 3)], wr[k], v);
         v = fmaf(fmaxf(v, 0.f), s, sh);
-        amax = fmaxf(amax, fabsf(v));
         const int y = y0 + r, x = x0 + c;
         if (y < p.H && x < p.W) {
             char* g = out + ((((size_t)b * p.H + y) * p.W + x) * p.out_cstride + p.out_coff) * 4 + (size_t)(lane >> 3) * 32 + (lane & 7) * 2;
             const lm_h16 h = lm_f2h(v);
+            unsigned short hb;
+            memcpy(&hb, &h, 2);
+            gmax = lm_pk_absmax_u16(gmax, hb);
             *reinterpret_cast<lm_h16*>(g) = h;
             *reinterpret_cast<lm_h16*>(g + 16) = lm_round_lo1(lm_f2h(v - lm_h2f(h)));
         }
     }
-    if (p.range_flag != nullptr && !(amax < kF16Guard)) atomicOr(p.range_flag, 1u);
+    if (p.range_flag != nullptr && lm_pk_out_of_f16_guard(gmax)) atomicOr(p.range_flag, 1u);
 }
 hipError_t launch_first_conv_h3(const FirstConvParams& p, hipStream_t stream) {
     const int tiles = ((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH);
