@@ -335,6 +335,15 @@ __device__ __forceinline__ float4 as_float4(const lm_h16x8& v) {
 
 // HEAD: the fused-head form of the epilogue (last decoder conv, labels only) -- a separate instantiation, so that the 16 other
 // launches of a forward do not carry its registers.
+// epilogue constants (bias, BN scale, BN shift) of 4 consecutive channels from the item's staged arrays
+#define H3P_EPI_READS(E, CL)                        \
+    do {                                            \
+        LM_LDS_READ128(E[0], ep + (CL) * 4, 0);     \
+        LM_LDS_READ128(E[1], ep + (CL) * 4, TN * 4); \
+        LM_LDS_READ128(E[2], ep + (CL) * 4, 2 * TN * 4); \
+    } while (0)
+#define H3P_EPI_CL(MG) (32 * ((MG) >> 2) + 8 * ((MG) & 3) + 4 * kb)
+
 template <int TAPS, bool G16, bool HEAD = false>
 __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptiles, int n_items, int xcd_order) {
     using SM = H3WSmem<TAPS, G16>;
@@ -593,16 +602,19 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                     const int bmask = (yl == 0 ? 1 : 0) | (yl == p.H - 1 ? 2 : 0) | (x0 + li == 0 ? 4 : 0) | (x0 + li == p.W - 1 ? 8 : 0);
                     const bool border = p.border_corr != nullptr && __any(bmask != 0);  // wave-uniform
                     float vv[8][4];
+                    lm_h16x8 ec[2][3];  // the constants of channel group mg + 1 are fetched under the arithmetic of group mg
+                    H3P_EPI_READS(ec[0], H3P_EPI_CL(0));
 #pragma unroll
                     for (int mg = 0; mg < 8; ++mg) {
                         const int mt = mg >> 2, g4 = mg & 3;
-                        const int cl = 32 * mt + 8 * g4 + 4 * kb;
-                        lm_h16x8 e0, e1, e2;
-                        LM_LDS_READ128(e0, ep + cl * 4, 0);
-                        LM_LDS_READ128(e1, ep + cl * 4, TN * 4);
-                        LM_LDS_READ128(e2, ep + cl * 4, 2 * TN * 4);
-                        LM_LDS_WAIT3(0, e0, e1, e2);
-                        const float4 bias = as_float4(e0), s = as_float4(e1), sh = as_float4(e2);
+                        const int cl = H3P_EPI_CL(mg);
+                        if (mg + 1 < 8) {
+                            H3P_EPI_READS(ec[(mg + 1) & 1], H3P_EPI_CL(mg + 1));
+                            LM_LDS_WAIT3(3, ec[mg & 1][0], ec[mg & 1][1], ec[mg & 1][2]);
+                        } else {
+                            LM_LDS_WAIT3(0, ec[mg & 1][0], ec[mg & 1][1], ec[mg & 1][2]);
+                        }
+                        const float4 bias = as_float4(ec[mg & 1][0]), s = as_float4(ec[mg & 1][1]), sh = as_float4(ec[mg & 1][2]);
                         float bb[4] = {bias.x, bias.y, bias.z, bias.w};
                         const float ss[4] = {s.x, s.y, s.z, s.w}, tt[4] = {sh.x, sh.y, sh.z, sh.w};
                         if (border) {  // deferred-shift input: the taps outside the image saw 0, not -T (ConvParamsH3::border_corr)
@@ -662,16 +674,19 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                 const int xl = G16 ? wcol : x0 + li;
                 const int bmask = (yl == 0 ? 1 : 0) | (yl == p.H - 1 ? 2 : 0) | (xl == 0 ? 4 : 0) | (xl == p.W - 1 ? 8 : 0);
                 const bool border = TAPS == 9 && p.border_corr != nullptr && __any(bmask != 0);  // wave-uniform
+                lm_h16x8 ec[2][3];  // the constants of channel group mg + 1 are fetched under the arithmetic of group mg
+                H3P_EPI_READS(ec[0], H3P_EPI_CL(0));
 #pragma unroll
                 for (int mg = 0; mg < 8; ++mg) {
                     const int mt = mg >> 2, g4 = mg & 3;
-                    const int cl = 32 * mt + 8 * g4 + 4 * kb;  // first of 4 consecutive local output channels
-                    lm_h16x8 e0, e1, e2;
-                    LM_LDS_READ128(e0, ep + cl * 4, 0);
-                    LM_LDS_READ128(e1, ep + cl * 4, TN * 4);
-                    LM_LDS_READ128(e2, ep + cl * 4, 2 * TN * 4);
-                    LM_LDS_WAIT3(0, e0, e1, e2);
-                    const float4 bias = as_float4(e0), s = as_float4(e1), sh = as_float4(e2);
+                    const int cl = H3P_EPI_CL(mg);  // first of 4 consecutive local output channels
+                    if (mg + 1 < 8) {
+                        H3P_EPI_READS(ec[(mg + 1) & 1], H3P_EPI_CL(mg + 1));
+                        LM_LDS_WAIT3(3, ec[mg & 1][0], ec[mg & 1][1], ec[mg & 1][2]);
+                    } else {
+                        LM_LDS_WAIT3(0, ec[mg & 1][0], ec[mg & 1][1], ec[mg & 1][2]);
+                    }
+                    const float4 bias = as_float4(ec[mg & 1][0]), s = as_float4(ec[mg & 1][1]), sh = as_float4(ec[mg & 1][2]);
                     float bb[4] = {bias.x, bias.y, bias.z, bias.w};
                     const float ss[4] = {s.x, s.y, s.z, s.w}, tt[4] = {sh.x, sh.y, sh.z, sh.w};
                     if (border) {

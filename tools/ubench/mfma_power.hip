@@ -103,6 +103,41 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// the same operand statistics through v_mfma_f32_16x16x32_f16: half the accumulator traffic per MAC, twice the operand traffic
+typedef float f4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void k16(float* out, unsigned long long* cyc, int iters, Fill f) {
+    h8 whi[2], wlo[2], ahi[2], alo[2];
+    for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 8; ++i) {
+            const unsigned id = (blockIdx.x * 512u + threadIdx.x) * 64u + j * 8 + i;
+            float w = urand(id), a = urand(id ^ 0x9e3779b9u);
+            if ((int)(urand(id ^ 0x2545f491u) * 50.f + 50.f) < f.zero_pct) a = 0.f;
+            _Float16 wh = (_Float16)w, ah = (_Float16)a;
+            whi[j][i] = wh; wlo[j][i] = (_Float16)(w - (float)wh); ahi[j][i] = ah; alo[j][i] = (_Float16)(a - (float)ah);
+        }
+    f4v c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0}, c4 = {0}, c5 = {0}, c6 = {0}, c7 = {0};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[0], ahi[0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[0], ahi[1], c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[1], ahi[0], c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[1], ahi[1], c3, 0, 0, 0);
+        c4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[0], alo[0], c4, 0, 0, 0);
+        c5 = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[0], alo[1], c5, 0, 0, 0);
+        c6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[1], alo[0], c6, 0, 0, 0);
+        c7 = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[1], alo[1], c7, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[0], ahi[0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[0], ahi[1], c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[1], ahi[0], c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[1], ahi[1], c3, 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0;
+    for (int i = 0; i < 4; ++i) s += c0[i] + c1[i] + c2[i] + c3[i] + c4[i] + c5[i] + c6[i] + c7[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
 int main() {
     float* out;
     unsigned long long* cyc;
@@ -147,6 +182,21 @@ int main() {
         for (int i = 0; i < blocks; ++i) avg += (double)cy[i] / blocks;
         const double flop = (double)blocks * (threads / 64) * iters * 12.0 * 32768.0;
         printf("%-62s %8.1f TFLOP/s  clock %.3f GHz\n", c.name, flop / ms / 1e9, avg / (ms * 1e6));  // s_memtime ticks per wall time
+    }
+    for (int zp : {0, 50}) {
+        Fill f{10, 10, 0, 0, 0, zp, 0};
+        int iters = 8000;
+        float ms = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+            (void)hipEventRecord(e0);
+            hipLaunchKernelGGL(k16, dim3(blocks), dim3(threads), 0, 0, out, cyc, iters, f);
+            (void)hipEventRecord(e1);
+            (void)hipEventSynchronize(e1);
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (pass == 0) iters = (int)(iters * (600.0 / ms));
+        }
+        const double flop = (double)blocks * (threads / 64) * iters * 12.0 * 16384.0;
+        printf("v_mfma_f32_16x16x32_f16, split (lo all), %2d%% of activations zero          %8.1f TFLOP/s\n", zp, flop / ms / 1e9);
     }
     return 0;
 }
