@@ -32,6 +32,17 @@ __device__ __forceinline__ lm_f32x16 lm_mfma_f32_32x32x16_f16(lm_h16x8 a, lm_h16
 #endif
 }
 
+// v_mfma_f32_16x16x32_f16 (gfx950): A[i=l&15][k=8*(l>>4)+j], B[k=8*(l>>4)+j][col=l&15]; D reg r of lane l is
+// (row i = 4*(l>>4)+r, col = l&15).  Half the accumulator traffic per MAC of the 32x32x16 form: under the chip's power budget
+// it sustains +15 % more FLOP/s on this network's operands (tools/ubench/mfma_power.hip).
+__device__ __forceinline__ lm_f32x4 lm_mfma_f32_16x16x32_f16(lm_h16x8 a, lm_h16x8 b, lm_f32x4 c) {
+#ifdef LM_EMU_BUILD
+    return lm_emu_mfma_f32_16x16x32_f16(a, b, c);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#endif
+}
+
 // Ordering point between LDS writes and reads of OTHER lanes of the same wave.  The hardware executes a
 // wave's LDS instructions in order, so nothing is emitted on the GPU; the test emulator runs lanes as
 // independent fibres and needs the rendezvous.

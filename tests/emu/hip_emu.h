@@ -409,6 +409,28 @@ inline lm_f32x16 lm_emu_mfma_f32_32x32x16_f16(lm_h16x8 a, lm_h16x8 b, lm_f32x16 
     return c;
 }
 
+// v_mfma_f32_16x16x32_f16: A[i=l&15][k=8*(l>>4)+j], B[k=8*(l>>4)+j][col=l&15]; D reg r of lane l: row 4*(l>>4)+r, col l&15.
+inline lm_f32x4 lm_emu_mfma_f32_16x16x32_f16(lm_h16x8 a, lm_h16x8 b, lm_f32x4 c) {
+    const int lane = lm_emu::linear_tid() & 63;
+    const int wv = lm_emu::linear_tid() >> 6;
+    static thread_local float As[16][64][8], Bs[16][64][8];  // per wave of the block
+    for (int j = 0; j < 8; ++j) {
+        As[wv][lane][j] = lm_h2f(a.v[j]);
+        Bs[wv][lane][j] = lm_h2f(b.v[j]);
+    }
+    lm_emu::wave_sync();
+    const int col = lane & 15, q = lane >> 4;
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * q + r;
+        float acc = c[r];
+        for (int kb = 0; kb < 4; ++kb)
+            for (int j = 0; j < 8; ++j) acc = fmaf(As[wv][16 * kb + i][j], Bs[wv][16 * kb + col][j], acc);
+        c[r] = acc;
+    }
+    lm_emu::wave_sync();
+    return c;
+}
+
 // global_load_lds_dwordx4: LDS destination = wave-uniform base + lane*16; per-lane global source.
 inline void lm_emu_global_load_lds16(const void* gsrc, void* lds_wave_base) {
     const int lane = lm_emu::linear_tid() & 63;

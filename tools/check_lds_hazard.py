@@ -49,7 +49,7 @@ def successors(blk_lines, nxt):
     return out
 
 
-for km in re.finditer(r"^(_ZN2lm14conv_igemm_h3pI[^:\n]*):[^\n]*\n(.*?)^\s*s_endpgm", asm, re.S | re.M):
+for km in re.finditer(r"^(_ZN2lm14conv_igemm_h3[pq]I[^:\n]*):[^\n]*\n(.*?)^\s*s_endpgm", asm, re.S | re.M):
     name, body = km.group(1), km.group(2)
     order, blocks, cur = ["<entry>"], {"<entry>": []}, "<entry>"
     in_asm = False
@@ -137,7 +137,7 @@ for km in re.finditer(r"^(_ZN2lm14conv_igemm_h3pI[^:\n]*):[^\n]*\n(.*?)^\s*s_end
 # hand-written lm_barrier_dma() carries it in the same asm statement) -- or it is the item-switch barrier that only orders LDS
 # accesses (lm_barrier_lds(), tagged LM_BARRIER_LDS_ONLY in the asm text): that one needs lgkmcnt(0) in front.
 barriers = lds_only = 0
-for km in re.finditer(r"^(_ZN2lm14conv_igemm_h3pI[^:\n]*):[^\n]*\n(.*?)^\s*s_endpgm", asm, re.S | re.M):
+for km in re.finditer(r"^(_ZN2lm14conv_igemm_h3[pq]I[^:\n]*):[^\n]*\n(.*?)^\s*s_endpgm", asm, re.S | re.M):
     name, raw_lines = km.group(1), km.group(2).splitlines()
     lines = [l.split(";")[0].strip() for l in raw_lines]
     for i, ln in enumerate(lines):
