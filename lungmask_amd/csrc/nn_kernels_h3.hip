@@ -357,8 +357,11 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
     constexpr int PSTR = 272;                   // staged pixel stride of the epilogue: 256 B of split data + 16 B pad
     constexpr int STAGE_BYTES = NW * 32 * PSTR;  // one 32-pixel row per wave
     // The epilogue staging area reuses the DMA buffer of the last chunk when it fits (3x3: 75 KiB), else it is extra.
-    constexpr int STAGE_EXTRA = STAGE_BYTES <= SM::BUF_BYTES ? 0 : STAGE_BYTES;
-    __shared__ __attribute__((aligned(1024))) char lds[2 * SM::BUF_BYTES + STAGE_EXTRA];
+    // A pipeline stage of the 1x1 form holds TWO chunk images (32 channels per barrier: with 16 the kernel is bound by the
+    // barrier + DMA round trip, not by anything it computes); the 3x3 form holds one.
+    constexpr int SUB = TAPS == 1 ? 2 : 1;
+    constexpr int STAGE_EXTRA = STAGE_BYTES <= SUB * SM::BUF_BYTES ? 0 : STAGE_BYTES;
+    __shared__ __attribute__((aligned(1024))) char lds[2 * SUB * SM::BUF_BYTES + STAGE_EXTRA];
     __shared__ __attribute__((aligned(16))) float epi[2][3][TN];  // bias, bn scale, bn shift of the item (double buffered)
     __shared__ __attribute__((aligned(16))) float hw[HEAD ? kMaxClasses * 64 + kMaxClasses : 4];  // fused head: weights, bias
 
@@ -485,7 +488,8 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
         } else if ((k & 1) == 0) {
             if (j < SM::A_PER_WAVE && wave + NW * j < d_nA) {
                 const int jj = j < SM::A_PER_WAVE ? j : 0;
-                lm_dma16(rsrcA, d_next ? voffN[jj] : voffC[jj], d_soffA, d_buf + (wave + NW * j) * 1024);
+                const unsigned vc = voffC[jj], vn = voffN[jj];  // (both read as VALUES: a select between the arrays themselves sends them to scratch)
+                lm_dma16(rsrcA, d_next ? vn : vc, d_soffA, d_buf + (wave + NW * j) * 1024);
             }
         } else {
             if (j < SM::W_PER_WAVE && wave + NW * j < d_nW)
@@ -510,11 +514,16 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
     item_voffs(b, y0, x0, voffC);
     int epar = 0;
     char* const buf0 = lds;
-    char* const buf1 = lds + SM::BUF_BYTES;
-    // prologue: chunk 0 of the first item, all pieces at once
+    char* const buf1 = lds + SUB * SM::BUF_BYTES;
+    // prologue: stage 0 of the first item, all pieces at once (set_dma's buffer argument counts chunk images)
     set_dma(false, b, n0, 0, 0, true, epar);
 #pragma unroll
     for (int k = 0; k < N_SLOTS; ++k) dma_slot(k);
+    if (SUB == 2) {
+        set_dma(false, b, n0, KC, 1, true, -1);
+#pragma unroll
+        for (int k = 0; k < N_SLOTS; ++k) dma_slot(k);
+    }
     lm_barrier_dma();
     LM_TRACE_INIT();
     while (true) {
@@ -564,16 +573,25 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                 H3P_MFMAS(g);
             }
         } else {
-            for (int ci = 0; ci < nchunks; ++ci) {
-                // chunk ci is resident in buffer ci & 1; stage the next one (or the next item's first) into the other
-                const char* as = (ci & 1) ? buf1 : buf0;
-                if (ci + 1 < nchunks) set_dma(false, b, n0, (ci + 1) * KC, (ci + 1) & 1, true, -1);
-                else set_dma(true, nb, nn0, 0, 0, have_next, epar ^ 1);
+            // 1x1: stage si = chunks 2 si, 2 si + 1 (two chunk images side by side), resident in stage buffer si & 1; the number of
+            // stages is even (checked by the launcher), so stage 0 of every item lives in buffer 0
+            const int nstages = nchunks / 2;
+            for (int si = 0; si < nstages; ++si) {
+                const char* as = (si & 1) ? buf1 : buf0;
+                const int nxt = ((si + 1) & 1) * 2;  // first chunk image of the other stage buffer
 #pragma unroll
-                for (int k = 0; k < N_SLOTS; ++k) dma_slot(k);
+                for (int sub = 0; sub < 2; ++sub) {  // stage the next two chunks (or the next item's first two) into the other buffer
+                    if (si + 1 < nstages) set_dma(false, b, n0, (2 * (si + 1) + sub) * KC, nxt + sub, true, -1);
+                    else set_dma(true, nb, nn0, sub * KC, sub, have_next, sub == 0 ? (epar ^ 1) : -1);
+#pragma unroll
+                    for (int k = 0; k < N_SLOTS; ++k) dma_slot(k);
+                }
                 H3P_READS(f, as, 0, 0);
-                H3P_WAITF(0, f);
+                H3P_READS(g, as + SM::BUF_BYTES, 0, 0);
+                H3P_WAITF(8, f);
                 H3P_MFMAS(f);
+                H3P_WAITF(0, g);
+                H3P_MFMAS(g);
                 lm_barrier_dma();
             }
         }
@@ -583,7 +601,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
             // All waves are done with the buffer of the last chunk (buffer 1): it becomes the staging area that turns the
             // accumulator layout (lane = pixel, 8 bytes per 4 couts: 64 scattered lines per store) into full
             // 256-byte pixel rows written 16 bytes per lane (the scattered form cost ~10 us per tile in the TA).
-            char* stage = (STAGE_EXTRA ? lds + 2 * SM::BUF_BYTES : buf1) + wave * (32 * PSTR);
+            char* stage = (STAGE_EXTRA ? lds + 2 * SUB * SM::BUF_BYTES : buf1) + wave * (32 * PSTR);
             unsigned gmax = 0u;  // running max of the |hi| halves this lane writes (f16 range guard, lm_pk_absmax_u16)
             const int bs = b + wsl;                      // slice this wave writes
             const int yb = y0 + (G16 ? 4 * (wave & 3) : 2 * wave);  // first image row of the wave's N-tile 0
@@ -1027,7 +1045,8 @@ __global__ __launch_bounds__(512) void conv_igemm_h3q(ConvParamsH3 p, int n_ptil
         } else if ((k & 1) == 0) {
             if (j < SM::A_PER_WAVE && wave + NW * j < d_nA) {
                 const int jj = j < SM::A_PER_WAVE ? j : 0;
-                lm_dma16(rsrcA, d_next ? voffN[jj] : voffC[jj], d_soffA, d_buf + (wave + NW * j) * 1024);
+                const unsigned vc = voffC[jj], vn = voffN[jj];  // (both read as VALUES: a select between the arrays themselves sends them to scratch)
+                lm_dma16(rsrcA, d_next ? vn : vc, d_soffA, d_buf + (wave + NW * j) * 1024);
             }
         } else {
             if (j < SM::W_PER_WAVE && wave + NW * j < d_nW)
@@ -1296,7 +1315,7 @@ static bool h3_persistent_ok(const ConvParamsH3& p, int taps) {
     // LM_H3_FALLBACK=1 forces the simple 4-wave kernel everywhere (it normally only serves odd widths): test hook
     static const bool wide_ok = [] { const char* e = getenv("LM_H3_FALLBACK"); return !(e && e[0] == '1'); }();
     const size_t slice_bytes = (size_t)p.H * p.W * p.in_cstride * 4;
-    return wide_ok && (p.W % 32 == 0 || p.W == 16) && (p.Cin / KC) % 2 == 0 && 2 * slice_bytes < 0x7fffffffull &&
+    return wide_ok && (p.W % 32 == 0 || p.W == 16) && (p.Cin / KC) % (taps == 1 ? 4 : 2) == 0 && 2 * slice_bytes < 0x7fffffffull &&
            (size_t)taps * p.Cout * p.Cin * 4 < 0x7fffffffull;
 }
 

@@ -1,5 +1,4 @@
-TAG=${1:-r02o}
-timeout 900 python -m pytest tests/test_gpu_forward.py -m gpu -q -x 2>&1 | tail -3
-echo "== conv_lab 16x16x32"; timeout 120 tools/ubench/conv_lab > gpurun_out/${TAG}_conv_lab_mma16.log 2>&1; cat gpurun_out/${TAG}_conv_lab_mma16.log
-echo "== conv_lab 32x32x16"; LM_H3_MMA=32 timeout 120 tools/ubench/conv_lab > gpurun_out/${TAG}_conv_lab_mma32.log 2>&1; cut -c1-44 gpurun_out/${TAG}_conv_lab_mma32.log
-for m in 16 32 16 32; do echo "LM_H3_MMA=$m"; LM_H3_MMA=$m timeout 120 python tools/ab_forward.py lungmask_amd/liblungmask_hip.so 2>&1 | grep "two lanes" | head -1; done
+TAG=${1:-r02q}
+timeout 300 python tools/ab_forward.py lungmask_amd/_ab/liblungmask_hip_r02a.so lungmask_amd/liblungmask_hip.so 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${TAG}_ab.log
+timeout 120 python tools/nn_perf.py 20 5 split_f16 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_nn_perf.log; grep "B=20\|conv1x1\|first\|upsample" gpurun_out/${TAG}_nn_perf.log
+timeout 600 python -m pytest tests/test_gpu_forward.py -m gpu -q -x 2>&1 | tail -2
