@@ -1393,11 +1393,12 @@ hipError_t launch_conv3x3_h3(const ConvParamsH3& p, hipStream_t stream) {
 hipError_t launch_conv1x1_h3(const ConvParamsH3& p, hipStream_t stream) { return launch_conv_h3_t<1>(p, stream); }
 
 // ---------------------------------------------------------------------------------------------
-// First layer (Cin = 1), fp32 arithmetic on the VALU, split output.  lane = output channel.
+// First layer (Cin = 1), fp32 arithmetic on the VALU, split output.  thread = (pixel, group of 8 output channels) with the
+// group fastest: the 8 threads of a pixel write its 256 bytes as 16 x 16-byte stores (one 32-byte hi8|lo8 group each), a wave
+// writes 8 consecutive pixels = 2 KiB contiguous.  (Round 1 had lane = channel and stored single halves.)
 __global__ __launch_bounds__(256) void first_conv_h3_kernel(FirstConvParams p) {
     __shared__ float tile[18 * 18];
-    __shared__ float wsm[9 * 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, grp = tid & 7, pl = tid >> 3;  // channel group, pixel lane 0..31
     const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
     int t = blockIdx.x;
     const int tx = t % tiles_x;
@@ -1412,29 +1413,41 @@ __global__ __launch_bounds__(256) void first_conv_h3_kernel(FirstConvParams p) {
         if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) v = p.in[((size_t)b * p.H + gy) * p.W + gx];
         tile[idx] = v;
     }
-    for (int idx = tid; idx < 9 * 64; idx += 256) wsm[idx] = p.w[idx];
-    __syncthreads();
-    float wr[9];
+    float wr[9][8], bias[8], s[8], sh[8];  // this thread's 8 channels: weights [tap][channel] (p.w is [9][64])
 #pragma unroll
-    for (int k = 0; k < 9; ++k) wr[k] = wsm[k * 64 + lane];
-    const float bias = p.bias[lane], s = p.bn_s[lane], sh = p.bn_t[lane];
+    for (int c = 0; c < 8; ++c) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wr[k][c] = p.w[k * 64 + 8 * grp + c];
+        bias[c] = p.bias[8 * grp + c];
+        s[c] = p.bn_s[8 * grp + c];
+        sh[c] = p.bn_t[8 * grp + c];
+    }
+    __syncthreads();
     char* out = reinterpret_cast<char*>(p.out);
     unsigned gmax = 0u;  // f16 range guard (running max of |hi| bit patterns)
-    for (int pix = 0; pix < 64; ++pix) {
-        const int r = 4 * wave + (pix >> 4), c = pix & 15;
-        float v = bias;
+    for (int pass = 0; pass < 8; ++pass) {  // 8 passes x 32 pixels = the 16 x 16 tile
+        const int pix = pass * 32 + pl, r = pix >> 4, c0 = pix & 15;
+        float in9[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) v = fmaf(tile[(r + k / 3) * 18 + c + (k % 3)], wr[k], v);
-        v = fmaf(fmaxf(v, 0.f), s, sh);
-        const int y = y0 + r, x = x0 + c;
+        for (int k = 0; k < 9; ++k) in9[k] = tile[(r + k / 3) * 18 + c0 + (k % 3)];
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float a = bias[c];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) a = fmaf(in9[k], wr[k][c], a);  // same chain as the per-channel form: bias, then taps 0..8
+            v[c] = fmaf(fmaxf(a, 0.f), s[c], sh[c]);
+        }
+        const int y = y0 + r, x = x0 + c0;
         if (y < p.H && x < p.W) {
-            char* g = out + ((((size_t)b * p.H + y) * p.W + x) * p.out_cstride + p.out_coff) * 4 + (size_t)(lane >> 3) * 32 + (lane & 7) * 2;
-            const lm_h16 h = lm_f2h(v);
-            unsigned short hb;
-            memcpy(&hb, &h, 2);
-            gmax = lm_pk_absmax_u16(gmax, hb);
-            *reinterpret_cast<lm_h16*>(g) = h;
-            *reinterpret_cast<lm_h16*>(g + 16) = lm_round_lo1(lm_f2h(v - lm_h2f(h)));
+            char* g = out + ((((size_t)b * p.H + y) * p.W + x) * p.out_cstride + p.out_coff) * 4 + (size_t)grp * 32;
+            uint2 h0, l0, h1, l1;
+            lm_split4(v[0], v[1], v[2], v[3], &h0, &l0);
+            lm_split4(v[4], v[5], v[6], v[7], &h1, &l1);
+            gmax = lm_pk_absmax_u16(lm_pk_absmax_u16(lm_pk_absmax_u16(lm_pk_absmax_u16(gmax, h0.x), h0.y), h1.x), h1.y);
+            const uint4 hi = {h0.x, h0.y, h1.x, h1.y}, lo = {l0.x, l0.y, l1.x, l1.y};
+            *reinterpret_cast<uint4*>(g) = hi;
+            *reinterpret_cast<uint4*>(g + 16) = lo;
         }
     }
     if (p.range_flag != nullptr && lm_pk_out_of_f16_guard(gmax)) atomicOr(p.range_flag, 1u);
