@@ -1469,51 +1469,51 @@ __device__ __forceinline__ void load_group(const char* g, float* v) {  // 32-byt
 }
 }  // namespace
 
-// Bilinear x2 (align_corners=False) on split tensors; thread = (output pixel, 8-channel group).
+// Bilinear x2 (align_corners=False) on split tensors; thread = (output pixel, 8-channel group), one block row per output image
+// row (no 64-bit index arithmetic), the 32-byte group written as two 16-byte stores.
 __global__ __launch_bounds__(256) void upsample2x_h3_kernel(UpsampleParams p) {
-    const int G = p.C >> 3;
+    const unsigned G = (unsigned)p.C >> 3;
     const int H2 = 2 * p.h, W2 = 2 * p.w;
-    const size_t total = (size_t)p.B * H2 * W2 * G;
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;  // element of the output row: x * G + g
+    if (e >= (unsigned)W2 * G) return;
+    const int x = (int)(e / G), g = (int)(e - (unsigned)x * G);
+    const int y = (int)blockIdx.y, b = (int)blockIdx.z;
     const char* in = reinterpret_cast<const char*>(p.in);
     char* out = reinterpret_cast<char*>(p.out);
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int g = (int)(idx % G);
-        size_t rest = idx / G;
-        const int x = (int)(rest % W2);
-        rest /= W2;
-        const int y = (int)(rest % H2);
-        const int b = (int)(rest / H2);
-        int ya, yb, xa, xb;
-        float wya, wyb, wxa, wxb;
-        {
-            const int i = y >> 1;
-            if (y & 1) { ya = i; yb = min(i + 1, p.h - 1); wya = 0.75f; wyb = 0.25f; }
-            else if (i == 0) { ya = 0; yb = 0; wya = 1.f; wyb = 0.f; }
-            else { ya = i - 1; yb = i; wya = 0.25f; wyb = 0.75f; }
-            const int j = x >> 1;
-            if (x & 1) { xa = j; xb = min(j + 1, p.w - 1); wxa = 0.75f; wxb = 0.25f; }
-            else if (j == 0) { xa = 0; xb = 0; wxa = 1.f; wxb = 0.f; }
-            else { xa = j - 1; xb = j; wxa = 0.25f; wxb = 0.75f; }
-        }
-        const char* base = in + (size_t)b * p.h * p.w * p.C * 4 + (size_t)g * 32;
-        float a00[8], a01[8], a10[8], a11[8], o[8];
-        load_group(base + ((size_t)ya * p.w + xa) * p.C * 4, a00);
-        load_group(base + ((size_t)ya * p.w + xb) * p.C * 4, a01);
-        load_group(base + ((size_t)yb * p.w + xa) * p.C * 4, a10);
-        load_group(base + ((size_t)yb * p.w + xb) * p.C * 4, a11);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = wya * (wxa * a00[k] + wxb * a01[k]) + wyb * (wxa * a10[k] + wxb * a11[k]);
-        char* dst = out + ((((size_t)b * H2 + y) * W2 + x) * p.out_cstride + p.out_coff) * 4 + (size_t)g * 32;
-        split_store4(dst, 0, o[0], o[1], o[2], o[3]);
-        split_store4(dst, 8, o[4], o[5], o[6], o[7]);
+    int ya, yb, xa, xb;
+    float wya, wyb, wxa, wxb;
+    {
+        const int i = y >> 1;
+        if (y & 1) { ya = i; yb = min(i + 1, p.h - 1); wya = 0.75f; wyb = 0.25f; }
+        else if (i == 0) { ya = 0; yb = 0; wya = 1.f; wyb = 0.f; }
+        else { ya = i - 1; yb = i; wya = 0.25f; wyb = 0.75f; }
+        const int j = x >> 1;
+        if (x & 1) { xa = j; xb = min(j + 1, p.w - 1); wxa = 0.75f; wxb = 0.25f; }
+        else if (j == 0) { xa = 0; xb = 0; wxa = 1.f; wxb = 0.f; }
+        else { xa = j - 1; xb = j; wxa = 0.25f; wxb = 0.75f; }
     }
+    const char* base = in + (size_t)b * p.h * p.w * p.C * 4 + (size_t)g * 32;
+    float a00[8], a01[8], a10[8], a11[8], o[8];
+    load_group(base + ((size_t)ya * p.w + xa) * p.C * 4, a00);
+    load_group(base + ((size_t)ya * p.w + xb) * p.C * 4, a01);
+    load_group(base + ((size_t)yb * p.w + xa) * p.C * 4, a10);
+    load_group(base + ((size_t)yb * p.w + xb) * p.C * 4, a11);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = wya * (wxa * a00[k] + wxb * a01[k]) + wyb * (wxa * a10[k] + wxb * a11[k]);
+    char* dst = out + ((((size_t)b * H2 + y) * W2 + x) * p.out_cstride + p.out_coff) * 4 + (size_t)g * 32;
+    uint2 h0, l0, h1, l1;
+    lm_split4(o[0], o[1], o[2], o[3], &h0, &l0);
+    lm_split4(o[4], o[5], o[6], o[7], &h1, &l1);
+    const uint4 hi = {h0.x, h0.y, h1.x, h1.y}, lo = {l0.x, l0.y, l1.x, l1.y};
+    *reinterpret_cast<uint4*>(dst) = hi;
+    *reinterpret_cast<uint4*>(dst + 16) = lo;
 }
 
 hipError_t launch_upsample2x_h3(const UpsampleParams& p, hipStream_t stream) {
     if ((p.C & 7) || (p.out_cstride & 7) || (p.out_coff & 7)) return hipErrorInvalidValue;
-    const size_t total = (size_t)p.B * 4 * p.h * p.w * (p.C >> 3);
-    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 16);
-    LM_LAUNCH(upsample2x_h3_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    const unsigned row_elems = (unsigned)(2 * p.w) * (unsigned)(p.C >> 3);
+    if (p.B > 65535 || 2 * p.h > 65535) return hipErrorInvalidValue;
+    LM_LAUNCH(upsample2x_h3_kernel, dim3((row_elems + 255) / 256, (unsigned)(2 * p.h), (unsigned)p.B), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 
