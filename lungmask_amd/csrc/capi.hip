@@ -1,9 +1,8 @@
 // extern "C" surface of liblungmask_hip.so (include/lungmask_hip.h).
-#include "engine.h"
-#ifndef LM_EMU_BUILD
 #include <chrono>
 #include <thread>
-#endif
+
+#include "engine.h"
 #include "post_kernels.h"
 #include "pre_kernels.h"
 
@@ -17,13 +16,7 @@ extern "C" {
 
 const char* lm_last_error(void) { return get_error(); }
 const char* lm_version(void) { return "lungmask_hip 0.1 (gfx950)"; }
-int lm_is_gpu_build(void) {
-#ifdef LM_EMU_BUILD
-    return 0;
-#else
-    return 1;
-#endif
-}
+int lm_is_gpu_build(void) { return LM_IS_GPU_BUILD; }
 
 int lm_engine_create(lm_engine** out, int device_id) {
     if (!out) return LM_ERR_INVALID;
@@ -48,15 +41,11 @@ int lm_engine_create(lm_engine** out, int device_id) {
     // streams the process created before -- e.g. torch.distributed's -- which cost 15 % in one start-up order); a stream of
     // another priority class always gets a queue of its own.  Lowest priority: the lane fills gaps, it never preempts.
     hipError_t err2;
-#ifndef LM_EMU_BUILD
     {
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         err2 = hipStreamCreateWithPriority(&e->stream2, hipStreamDefault, least);
     }
-#else
-    err2 = hipStreamCreate(&e->stream2);
-#endif
     if (err2 != hipSuccess || hipEventCreate(&e->ev_fork) != hipSuccess || hipEventCreate(&e->ev_join) != hipSuccess) {
         set_error("creating the second forward lane failed");
         e->stream2 = nullptr;
@@ -344,7 +333,6 @@ int lm_apply_host(lm_engine* e, int slot, int fill_slot, const void* vol_host, i
     if (batch_size <= 0) batch_size = 20;
     const int head = (e->n_streams > 1 ? 2 : 1) * batch_size;
     const bool split = n > head;
-#ifndef LM_EMU_BUILD
     if (split && !e->copy_stream) {
         if (hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->tail_ready, hipEventDisableTiming) != hipSuccess) {
             set_error("lm_apply_host: creating the copy stream failed");
@@ -388,17 +376,11 @@ int lm_apply_host(lm_engine* e, int slot, int fill_slot, const void* vol_host, i
     helper.join();
     if (rc != LM_OK) return rc;
     const double t_join = ms_since(t_start);
-#else
-    LM_HIP(hipMemcpyAsync(e->app.vol.p, vol_host, nvox * esz, hipMemcpyHostToDevice, e->stream));
-    LM_TRY(apply_volume(e, slot, fill_slot, e->app.vol.p, dtype, n, h, w, batch_size, volume_postprocessing, e->app.out.as<uint8_t>()));
-#endif
     LM_HIP(hipMemcpyAsync(out_host, e->app.out.p, nvox, hipMemcpyDeviceToHost, e->stream));
     LM_HIP(hipStreamSynchronize(e->stream));
-#ifndef LM_EMU_BUILD
     if (timing)
         fprintf(stderr, "lm_apply_host: head H2D returned %.2f ms | helper: tail enqueued %.2f, pages touched %.2f | hot path returned %.2f | joined %.2f | D2H done %.2f ms\n", t_head,
                 t_tail, t_touch, t_apply, t_join, ms_since(t_start));
-#endif
     return LM_OK;
 }
 

@@ -14,6 +14,12 @@ typedef float lm_f32x16 __attribute__((ext_vector_type(16)));
 typedef float lm_f32x4 __attribute__((ext_vector_type(4)));
 #endif
 #include <cstdint>
+// 1 for the hipcc/gfx950 product build, 0 for the g++ test emulation (lm_is_gpu_build(): the binding refuses the latter)
+#ifdef LM_EMU_BUILD
+#define LM_IS_GPU_BUILD 0
+#else
+#define LM_IS_GPU_BUILD 1
+#endif
 
 // ---- fp16 pieces of the split-f16 ("3-product") path -------------------------------------------
 #ifndef LM_EMU_BUILD
@@ -168,7 +174,10 @@ __device__ __forceinline__ void lm_barrier_lds() { asm volatile("s_waitcnt lgkmc
 // ---- in-kernel cycle accounting of the persistent conv kernel (lab builds only: -DLM_H3_TRACE) ------------------
 // Per wave, the shader-clock cycles between consecutive marks are summed per category and written to lm_h3_trace_ptr
 // ([workgroup][wave][8] unsigned) at kernel end.  The product build compiles all of it to nothing.
-#if defined(LM_H3_TRACE) && !defined(LM_EMU_BUILD)
+#if defined(LM_H3_TRACE) && defined(LM_EMU_BUILD)
+#undef LM_H3_TRACE  // the trace reads the shader clock: hardware only
+#endif
+#ifdef LM_H3_TRACE
 extern __device__ unsigned* lm_h3_trace_ptr;
 #define LM_TRACE_INIT()                                     \
     unsigned tr_last_ = (unsigned)__builtin_amdgcn_s_memtime(); \

@@ -26,7 +26,7 @@
 
 #include "nn_kernels.h"
 
-#if defined(LM_H3_TRACE) && !defined(LM_EMU_BUILD)
+#ifdef LM_H3_TRACE  // lab builds only (tools/ubench/conv_lab.hip)
 __device__ unsigned* lm_h3_trace_ptr = nullptr;
 #endif
 
@@ -1328,13 +1328,9 @@ static hipError_t launch_conv_h3_t(const ConvParamsH3& p, hipStream_t stream) {
         // LM_H3_ORDER: 0 cout-major everywhere, 1 XCD-aware pixel-tile-major everywhere, default: per layer (see the kernel)
         static const int order_env = [] { const char* e = getenv("LM_H3_ORDER"); return e ? atoi(e) : -1; }();
         static const int n_cu = [] {
-#ifdef LM_EMU_BUILD
-            return 4;
-#else
             int dev = 0, n = 256;
             if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
             return n > 0 ? n : 256;
-#endif
         }();
         // sub-batches whose input tensor stays below 2 GiB (an even number of slices: the 16-wide geometry pairs them)
         const size_t slice_bytes = (size_t)p.H * p.W * p.in_cstride * 4;
