@@ -114,10 +114,10 @@ struct HostBuf {
 
 struct PostWorkspace {
     HostBuf h_area, h_labval, h_recs;
-    DevBuf parent, ids, rank, bgparent, blockcnt, area, labval, recs, lut, mapped, bg, out, scalars;
+    DevBuf parent, ids, rank, bgparent, blockcnt, area, labval, recs, lut, mapped, bg, out, scalars, bbox;
     void release() {
         parent.release(); ids.release(); rank.release(); bgparent.release(); blockcnt.release(); area.release(); labval.release();
-        recs.release(); lut.release(); mapped.release(); bg.release(); out.release(); scalars.release();
+        recs.release(); lut.release(); mapped.release(); bg.release(); out.release(); scalars.release(); bbox.release();
         h_area.release(); h_labval.release(); h_recs.release();
     }
 };

@@ -243,21 +243,58 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
     LM_HIP(hipStreamSynchronize(s));
     uint8_t* out = ws.out.as<uint8_t>();
     LM_HIP(hipMemsetAsync(out, 0, nvox, s));
+    // bounding boxes of the kept components: the hole fill of a label only has to look inside its box (post_kernels.h: Box)
+    int keep_roots[256], bbox[256 * 6];
+    bool any = false;
+    for (int label = 0; label < 256; ++label) {
+        keep_roots[label] = (label && best[label]) ? (int)(unsigned)(best[label] & 0xffffffffull) : -1;
+        any = any || keep_roots[label] >= 0;
+        for (int k = 0; k < 6; ++k) bbox[6 * label + k] = k < 3 ? 0x7fffffff : -1;
+    }
+    if (any && N > 1) {
+        LM_TRY(ws.bbox.reserve((256 + 256 * 6) * sizeof(int)));
+        int* kr_dev = ws.bbox.as<int>();
+        int* bbox_dev = kr_dev + 256;
+        LM_HIP(hipMemcpyAsync(kr_dev, keep_roots, sizeof keep_roots, hipMemcpyHostToDevice, s));
+        LM_HIP(hipMemcpyAsync(bbox_dev, bbox, sizeof bbox, hipMemcpyHostToDevice, s));
+        {
+            ProfScope ps(e, "post_component_bbox", (double)nvox * 5);
+            LM_K(component_bboxes(parent, mapped, kr_dev, bbox_dev, d, s));
+        }
+        LM_HIP(hipMemcpyAsync(bbox, bbox_dev, sizeof bbox, hipMemcpyDeviceToHost, s));
+        LM_HIP(hipStreamSynchronize(s));
+    }
     for (int label = 1; label < 256; ++label) {
         if (!best[label]) continue;
-        const int keep_root = (int)(unsigned)(best[label] & 0xffffffffull);
-        LM_K(complement_of_component(parent, keep_root, ws.bg.as<uint8_t>(), nvox, s));
-        {
-            ProfScope ps(e, "post_ccl6_background", (double)nvox * 9);
-            LM_K(ccl_label(ws.bg.as<uint8_t>(), ws.bgparent.as<int>(), d, false, s));
-        }
-        if (N == 1)  // skimage.morphology.area_closing(area_threshold=64)                       utils.py:344-350
+        const int keep_root = keep_roots[label];
+        if (N == 1) {  // skimage.morphology.area_closing(area_threshold=64): areas of whole components -> whole slice   utils.py:344-350
+            LM_K(complement_of_component(parent, keep_root, ws.bg.as<uint8_t>(), nvox, s));
+            {
+                ProfScope ps(e, "post_ccl6_background", (double)nvox * 9);
+                LM_K(ccl_label(ws.bg.as<uint8_t>(), ws.bgparent.as<int>(), d, false, s));
+            }
             LM_K(flag_large_components(ws.bgparent.as<int>(), ids, 64, nvox, s));
-        else  // fill_voids.fill: background not 6-connected to a face of the volume             utils.py:352
-            LM_K(flag_face_components(ws.bgparent.as<int>(), ids, d, s));
-        {
             ProfScope ps(e, "post_fill_write", (double)nvox * 13);
             LM_K(fill_write(parent, keep_root, ws.bgparent.as<int>(), ids, (uint8_t)label, out, nvox, s));
+            continue;
+        }
+        // fill_voids.fill: background not 6-connected to a face of the volume                    utils.py:352
+        const int* bb = bbox + 6 * label;
+        Box box;
+        box.z0 = std::max(bb[0] - 1, 0);
+        box.y0 = std::max(bb[1] - 1, 0);
+        box.x0 = std::max(bb[2] - 1, 0);
+        box.d = Dims{std::min(bb[3] + 2, N) - box.z0, std::min(bb[4] + 2, H) - box.y0, std::min(bb[5] + 2, W) - box.x0};
+        const size_t nbox = box.d.nvox();
+        LM_K(complement_of_component_box(parent, keep_root, d, box, ws.bg.as<uint8_t>(), s));
+        {
+            ProfScope ps(e, "post_ccl6_background", (double)nbox * 9);
+            LM_K(ccl_label(ws.bg.as<uint8_t>(), ws.bgparent.as<int>(), box.d, false, s));
+        }
+        LM_K(flag_face_components(ws.bgparent.as<int>(), ids, box.d, s));
+        {
+            ProfScope ps(e, "post_fill_write", (double)nbox * 13);
+            LM_K(fill_write_box(parent, keep_root, ws.bgparent.as<int>(), ids, (uint8_t)label, out, d, box, s));
         }
     }
     LM_HIP(hipMemcpyAsync(lab, out, nvox, hipMemcpyDeviceToDevice, s));

@@ -47,6 +47,25 @@ hipError_t flag_large_components(const int* bgparent, int* flags, int threshold,
 hipError_t fill_write(const int* parent, int keep_root, const int* bgparent, const int* flags, uint8_t label, uint8_t* out, size_t nvox,
                       hipStream_t s);
 
+// Hole filling confined to a box.  A background voxel of the kept component's complement can only be a hole INSIDE the
+// component's bounding box: with the box grown by one voxel (clipped at the volume) a background component is "outside" exactly
+// when it reaches a face of the box -- the grown shell lies outside the bounding box, hence is all background and connected to
+// the volume's faces; where the box was clipped its face IS a face of the volume.  So the 6-connected background labelling, the
+// face flags and the final write run on the box only (a lobe's box is a fraction of a 300 x 512 x 512 volume).
+struct Box {
+    int z0, y0, x0;  // origin in the volume
+    Dims d;          // extent
+};
+// bbox[label] = {zmin, ymin, xmin, zmax, ymax, xmax} (ints; mins preset to INT_MAX, maxs to -1 by the caller) of the voxels whose
+// root is keep_root[lab[v]] (keep_root: 256 ints, -1 for absent labels)
+hipError_t component_bboxes(const int* parent, const uint8_t* lab, const int* keep_root, int* bbox, Dims d, hipStream_t s);
+// bg[compact index in the box] = (parent[v] != keep_root)
+hipError_t complement_of_component_box(const int* parent, int keep_root, Dims d, Box box, uint8_t* bg, hipStream_t s);
+// out[v] = label for the voxels of the box that are in the kept component or in an unflagged background component of the
+// box-local labelling bgparent/flags
+hipError_t fill_write_box(const int* parent, int keep_root, const int* bgparent, const int* flags, uint8_t label, uint8_t* out, Dims d, Box box,
+                          hipStream_t s);
+
 // ---- slab-sharded post-processing (slab_engine.hip): the same passes on ONE rank's slices, plus the few
 //      planes/tables that tie the slabs together.  "atom" = component of the slab-local labelling (dense id).
 // Halo neighbours in boundary records are tagged: id | HALO_LO (atom of the previous rank's last slice) or

@@ -421,6 +421,69 @@ __global__ __launch_bounds__(TPB) void fill_write_kernel(const int* __restrict__
     }
 }
 
+// ---- hole filling confined to the kept component's bounding box (post_kernels.h: Box) -----------------------------
+__global__ __launch_bounds__(TPB) void component_bboxes_kernel(const int* __restrict__ P, const uint8_t* __restrict__ lab, const int* __restrict__ keep_root,
+                                                               int* bbox, Dims d) {
+    __shared__ int kr[256];
+    __shared__ int sb[256][6];  // per label: mins then maxs, of this workgroup's voxels
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        kr[i] = keep_root[i];
+        sb[i][0] = sb[i][1] = sb[i][2] = 0x7fffffff;
+        sb[i][3] = sb[i][4] = sb[i][5] = -1;
+    }
+    __syncthreads();
+    const size_t nvox = d.nvox();
+    const size_t HW = (size_t)d.H * d.W;
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x) {
+        const int L = lab[v];
+        if (!L || P[v] != kr[L]) continue;
+        const int x = (int)(v % d.W), y = (int)((v / d.W) % d.H), z = (int)(v / HW);
+        // (most voxels of a workgroup's contiguous range do not move the extremes: test before the LDS atomic)
+        if (z < sb[L][0]) atomicMin(&sb[L][0], z);
+        if (y < sb[L][1]) atomicMin(&sb[L][1], y);
+        if (x < sb[L][2]) atomicMin(&sb[L][2], x);
+        if (z > sb[L][3]) atomicMax(&sb[L][3], z);
+        if (y > sb[L][4]) atomicMax(&sb[L][4], y);
+        if (x > sb[L][5]) atomicMax(&sb[L][5], x);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        if (sb[i][3] < 0) continue;
+        atomicMin(&bbox[6 * i + 0], sb[i][0]);
+        atomicMin(&bbox[6 * i + 1], sb[i][1]);
+        atomicMin(&bbox[6 * i + 2], sb[i][2]);
+        atomicMax(&bbox[6 * i + 3], sb[i][3]);
+        atomicMax(&bbox[6 * i + 4], sb[i][4]);
+        atomicMax(&bbox[6 * i + 5], sb[i][5]);
+    }
+}
+
+__global__ __launch_bounds__(TPB) void complement_box_kernel(const int* __restrict__ P, int keep_root, Dims d, Box box, uint8_t* __restrict__ bg) {
+    const size_t n = box.d.nvox();
+    const size_t hw = (size_t)box.d.H * box.d.W;
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(c % box.d.W), y = (int)((c / box.d.W) % box.d.H), z = (int)(c / hw);
+        const size_t v = ((size_t)(box.z0 + z) * d.H + (box.y0 + y)) * d.W + (box.x0 + x);
+        bg[c] = (P[v] != keep_root) ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void fill_write_box_kernel(const int* __restrict__ P, int keep_root, const int* __restrict__ BP, const int* __restrict__ flags,
+                                                             uint8_t label, uint8_t* out, Dims d, Box box) {
+    const size_t n = box.d.nvox();
+    const size_t hw = (size_t)box.d.H * box.d.W;
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(c % box.d.W), y = (int)((c / box.d.W) % box.d.H), z = (int)(c / hw);
+        const size_t v = ((size_t)(box.z0 + z) * d.H + (box.y0 + y)) * d.W + (box.x0 + x);
+        bool on = P[v] == keep_root;
+        if (!on) {
+            const int r = BP[c];
+            on = r >= 0 && flags[r] == 0;
+        }
+        if (on) out[v] = label;
+    }
+}
+
 // ---- slab-sharded mode --------------------------------------------------------------------------
 __global__ __launch_bounds__(TPB) void atom_first_kernel(const int* __restrict__ P, const int* __restrict__ rank, int* first, int voxel_base, size_t nvox) {
     for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x)
@@ -618,6 +681,22 @@ hipError_t flag_large_components(const int* bgparent, int* flags, int threshold,
 hipError_t fill_write(const int* parent, int keep_root, const int* bgparent, const int* flags, uint8_t label, uint8_t* out, size_t nvox,
                       hipStream_t s) {
     LM_LAUNCH(fill_write_kernel, dim3(grid_for(nvox)), dim3(TPB), 0, s, parent, keep_root, bgparent, flags, label, out, nvox);
+    return hipGetLastError();
+}
+
+hipError_t component_bboxes(const int* parent, const uint8_t* lab, const int* keep_root, int* bbox, Dims d, hipStream_t s) {
+    LM_LAUNCH(component_bboxes_kernel, dim3(grid_for(d.nvox(), 64 * 64, 2048)), dim3(TPB), 0, s, parent, lab, keep_root, bbox, d);
+    return hipGetLastError();
+}
+
+hipError_t complement_of_component_box(const int* parent, int keep_root, Dims d, Box box, uint8_t* bg, hipStream_t s) {
+    LM_LAUNCH(complement_box_kernel, dim3(grid_for(box.d.nvox())), dim3(TPB), 0, s, parent, keep_root, d, box, bg);
+    return hipGetLastError();
+}
+
+hipError_t fill_write_box(const int* parent, int keep_root, const int* bgparent, const int* flags, uint8_t label, uint8_t* out, Dims d, Box box,
+                          hipStream_t s) {
+    LM_LAUNCH(fill_write_box_kernel, dim3(grid_for(box.d.nvox())), dim3(TPB), 0, s, parent, keep_root, bgparent, flags, label, out, d, box);
     return hipGetLastError();
 }
 

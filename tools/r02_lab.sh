@@ -1,7 +1,8 @@
-# Round-end evidence run: parity suite, smoke, distributed path with a world of one, bench (3 configs), rocprofv3 stats + PMC + MFMA utilisation
-TAG=${1:-r02}
-bash tools/gpu_round_check.sh $TAG 2>&1 | tail -12
-for c in 3 4; do timeout 300 python bench.py --config $c --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_${TAG}_config$c.json; done
-TAG=$TAG bash tools/pmc_mfma.sh 2>&1 | tail -3
-timeout 120 python tools/nn_perf.py 20 5 split_f16 2>&1 | grep -v amdgpu > gpurun_out/nn_perf_${TAG}.log
-timeout 60 python tools/host_boundary.py > gpurun_out/host_boundary_${TAG}.log 2>&1; tail -1 gpurun_out/host_boundary_${TAG}.log
+TAG=${1:-r02v}
+timeout 900 python -m pytest tests/test_gpu_prepost.py tests/test_gpu_apply.py tests/test_gpu_fullsize.py -m gpu -q -x 2>&1 | tail -3
+for c in 2 4; do timeout 300 python bench.py --config $c --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_c$c.json; python - <<PY
+import json
+d=json.load(open("gpurun_out/${TAG}_bench_c$c.json"))
+print("config $c:", d["value"], d["ms_per_step"], {k:v for k,v in d["stages_ms_per_step"].items() if k.startswith("post")})
+PY
+done
