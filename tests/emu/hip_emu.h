@@ -67,6 +67,9 @@ enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyHostToHost };
 inline const char* hipGetErrorString(hipError_t e) { return e == 0 ? "success" : "emu error"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
+constexpr unsigned hipHostRegisterDefault = 0;
+inline hipError_t hipHostRegister(void*, size_t, unsigned) { return hipErrorInvalidValue; }  // the emulator takes the page-touch branch
+inline hipError_t hipHostUnregister(void*) { return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t n) {
