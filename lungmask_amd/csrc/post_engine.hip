@@ -283,8 +283,8 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
         Box box;
         box.z0 = std::max(bb[0] - 1, 0);
         box.y0 = std::max(bb[1] - 1, 0);
-        box.x0 = std::max(bb[2] - 1, 0);
-        box.d = Dims{std::min(bb[3] + 2, N) - box.z0, std::min(bb[4] + 2, H) - box.y0, std::min(bb[5] + 2, W) - box.x0};
+        box.x0 = std::max(bb[2] - 1, 0) & ~3;  // x extent widened to multiples of 4 (a larger box is as exact): the row-wise labelling kernel applies
+        box.d = Dims{std::min(bb[3] + 2, N) - box.z0, std::min(bb[4] + 2, H) - box.y0, std::min((bb[5] + 2 + 3) & ~3, W) - box.x0};
         const size_t nbox = box.d.nvox();
         LM_K(complement_of_component_box(parent, keep_root, d, box, ws.bg.as<uint8_t>(), s));
         {

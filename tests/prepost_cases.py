@@ -76,6 +76,23 @@ def check_postprocess_random(eng, seeds, shape=(7, 40, 36), nlab=4):
             assert np.array_equal(out, ref), (seed, spare, skip, int((out != ref).sum()))
 
 
+def check_postprocess_wide_rows(eng):
+    """Rows longer than one 256-voxel piece of the row-wise labelling kernels (ccl_*_rows_kernel): unions across the piece
+    boundaries, a last piece of 8 voxels, and a width that is not a multiple of 4 (the voxel-wise kernels)."""
+    from oracle.make_golden import random_blobs
+
+    for seed, shape in ((21, (3, 6, 520)), (22, (2, 5, 768)), (23, (3, 6, 258))):
+        rng = np.random.default_rng(seed)
+        lab = random_blobs(rng, shape, 3, 14, 0.2)
+        lab[:, 1:4, 200:330] = 2  # a solid bar through the boundaries at x = 256 (and 512 where it reaches)
+        lab[0, 2, 250:262] = 0    # ... with a hole on one of them
+        lab[-1, :, -9:] = 1
+        for spare, skip in (((), 3), ((), 1)):
+            out = eng.postprocess(lab, spare=spare, skip_below=skip)
+            ref = po.postprocessing(lab.copy(), spare=list(spare), skip_below=skip)
+            assert np.array_equal(out, ref), (shape, skip, int((out != ref).sum()))
+
+
 def check_fuse(eng):
     from oracle.make_golden import random_blobs
 
