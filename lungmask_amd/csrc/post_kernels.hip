@@ -22,6 +22,15 @@ inline unsigned grid_for(size_t n, int per_block = TPB, unsigned cap = 256 * 32)
     return (unsigned)std::min<size_t>(b, cap);
 }
 
+// (x, y, z) of a flat voxel index.  Every volume here has < 2^31 voxels (post_engine.hip refuses larger ones: parents are ints), so
+// two 32-bit divisions do what three 64-bit ones (~100 instructions each on this ISA) did.
+__device__ __forceinline__ void split3(size_t flat, int H, int W, int& x, int& y, int& z) {
+    const unsigned f = (unsigned)flat, q = f / (unsigned)W;
+    x = (int)(f - q * (unsigned)W);
+    z = (int)(q / (unsigned)H);
+    y = (int)(q - (unsigned)z * (unsigned)H);
+}
+
 __device__ __forceinline__ int find_root(const int* P, int x) {
     const volatile int* vp = P;
     int p;
@@ -89,7 +98,8 @@ __global__ __launch_bounds__(TPB) void ccl_merge_kernel(const uint8_t* __restric
     for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x) {
         const uint8_t L = lab[v];
         if (!L) continue;
-        const int x = (int)(v % d.W), y = (int)((v / d.W) % d.H), z = (int)(v / HW);
+        int x, y, z;
+            split3(v, d.H, d.W, x, y, z);
         const bool left_same = x > 0 && lab[v - 1] == L;
         const bool right_same = x + 1 < d.W && lab[v + 1] == L;
         if (left_same && (v & 63) == 0) unite(P, (int)v, (int)(v - 1));
@@ -189,7 +199,16 @@ __global__ __launch_bounds__(TPB) void ccl_merge_rows_kernel(const uint8_t* __re
         if (lane == 0) wl = x > 0 ? lab[v - 1] : 0u;
         if (lane == 63) wr = (in && x + 4 < W) ? lab[v + 4] : 0u;
         const unsigned long long mine = ((unsigned long long)wr << 40) | ((unsigned long long)w << 8) | wl;
-        if (lane == 0 && (w & 0xffu) != 0 && (w & 0xffu) == wl) unite(P, v, v - 1);  // runs are pre-connected inside a piece only
+        // A union is a chain of 3-5 dependent L2 accesses, and a lane meets at most a few: they are queued (two slots, then inline) and
+        // made after the scan, all lanes together -- one or two latency episodes per wave instead of one per (row, voxel) site.
+        int qa0 = 0, qb0 = 0, qa1 = 0, qb1 = 0, nq = 0;
+        auto push = [&](int a, int b) {
+            if (nq == 0) qa0 = a, qb0 = b;
+            else if (nq == 1) qa1 = a, qb1 = b;
+            else unite(P, a, b);
+            ++nq;
+        };
+        if (lane == 0 && (w & 0xffu) != 0 && (w & 0xffu) == wl) push(v, v - 1);  // runs are pre-connected inside a piece only
         // a row's word for this lane plus the voxels left and right of it (as bytes 0 and 5); off: wave-uniform, a multiple of 4
         auto load_row = [&](int off, unsigned& uw) {
             const int u = v + off;
@@ -212,10 +231,10 @@ __global__ __launch_bounds__(TPB) void ccl_merge_rows_kernel(const uint8_t* __re
                 const unsigned uc = (unsigned)(theirs >> (8 * j + 8)) & 0xffu, ulj = (unsigned)(theirs >> (8 * j)) & 0xffu,
                                urj = (unsigned)(theirs >> (8 * j + 16)) & 0xffu;
                 if (uc == L) {
-                    if (!(left_same && ulj == L)) unite(P, v + j, u + j);
+                    if (!(left_same && ulj == L)) push(v + j, u + j);
                 } else if (C26) {
-                    if (!left_same && ulj == L) unite(P, v + j, u + j - 1);
-                    if (!right_same && urj == L) unite(P, v + j, u + j + 1);
+                    if (!left_same && ulj == L) push(v + j, u + j - 1);
+                    if (!right_same && urj == L) push(v + j, u + j + 1);
                 }
             }
         };
@@ -243,6 +262,8 @@ __global__ __launch_bounds__(TPB) void ccl_merge_rows_kernel(const uint8_t* __re
                 if (y + 1 < d.H) join_row(-HW + W, rbb, wb);
             }
         }
+        if (nq > 0) unite(P, qa0, qb0);
+        if (nq > 1) unite(P, qa1, qb1);
     }
 }
 
@@ -424,7 +445,8 @@ __global__ __launch_bounds__(TPB) void boundary_records_kernel(const int* __rest
         int nb[6] = {0, 0, 0, 0, 0, 0};  // descending, distinct, zero padded
         if (v < v1) a = ids[v];
         if (a) {
-            const int x = (int)(v % d.W), y = (int)((v / d.W) % d.H), z = (int)(v / HW);
+            int x, y, z;
+            split3(v, d.H, d.W, x, y, z);
             auto add = [&](int b) {
                 if (b == 0 || b == a) return;
 #pragma unroll
@@ -545,7 +567,8 @@ __global__ __launch_bounds__(TPB) void flag_faces_kernel(const int* __restrict__
     const size_t nvox = d.nvox();
     const size_t HW = (size_t)d.H * d.W;
     for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)(v % d.W), y = (int)((v / d.W) % d.H), z = (int)(v / HW);
+        int x, y, z;
+            split3(v, d.H, d.W, x, y, z);
         if (x == 0 || y == 0 || z == 0 || x == d.W - 1 || y == d.H - 1 || z == d.N - 1) {
             const int r = BP[v];
             if (r >= 0) flags[r] = 1;
@@ -586,7 +609,8 @@ __global__ __launch_bounds__(TPB) void component_bboxes_kernel(const int* __rest
     for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x) {
         const int L = lab[v];
         if (!L || P[v] != kr[L]) continue;
-        const int x = (int)(v % d.W), y = (int)((v / d.W) % d.H), z = (int)(v / HW);
+        int x, y, z;
+            split3(v, d.H, d.W, x, y, z);
         // (most voxels of a workgroup's contiguous range do not move the extremes: test before the LDS atomic)
         if (z < sb[L][0]) atomicMin(&sb[L][0], z);
         if (y < sb[L][1]) atomicMin(&sb[L][1], y);
@@ -611,7 +635,8 @@ __global__ __launch_bounds__(TPB) void complement_box_kernel(const int* __restri
     const size_t n = box.d.nvox();
     const size_t hw = (size_t)box.d.H * box.d.W;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)(c % box.d.W), y = (int)((c / box.d.W) % box.d.H), z = (int)(c / hw);
+        int x, y, z;
+        split3(c, box.d.H, box.d.W, x, y, z);
         const size_t v = ((size_t)(box.z0 + z) * d.H + (box.y0 + y)) * d.W + (box.x0 + x);
         bg[c] = (P[v] != keep_root) ? 1 : 0;
     }
@@ -622,7 +647,8 @@ __global__ __launch_bounds__(TPB) void fill_write_box_kernel(const int* __restri
     const size_t n = box.d.nvox();
     const size_t hw = (size_t)box.d.H * box.d.W;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)(c % box.d.W), y = (int)((c / box.d.W) % box.d.H), z = (int)(c / hw);
+        int x, y, z;
+        split3(c, box.d.H, box.d.W, x, y, z);
         const size_t v = ((size_t)(box.z0 + z) * d.H + (box.y0 + y)) * d.W + (box.x0 + x);
         bool on = P[v] == keep_root;
         if (!on) {
@@ -643,7 +669,8 @@ __global__ __launch_bounds__(TPB) void atom_face_flags_kernel(const int* __restr
     const size_t nvox = d.nvox();
     const size_t HW = (size_t)d.H * d.W;
     for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)(v % d.W), y = (int)((v / d.W) % d.H), z = (int)(v / HW);
+        int x, y, z;
+            split3(v, d.H, d.W, x, y, z);
         if (x == 0 || y == 0 || x == d.W - 1 || y == d.H - 1 || (zlo_face && z == 0) || (zhi_face && z == d.N - 1)) {
             const int a = ids[v];
             if (a) flags[a] = 1;
