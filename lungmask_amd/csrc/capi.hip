@@ -343,7 +343,6 @@ int lm_apply_host(lm_engine* e, int slot, int fill_slot, const void* vol_host, i
     const auto t_start = std::chrono::steady_clock::now();
     auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     double t_tail = 0, t_touch = 0;
-    bool out_pinned = false;
     e->tail_enqueued.store(0, std::memory_order_release);
     std::thread helper([&] {
         hipError_t terr = hipSuccess;
@@ -357,16 +356,12 @@ int lm_apply_host(lm_engine* e, int slot, int fill_slot, const void* vol_host, i
         }
         e->tail_enqueued.store(terr == hipSuccess ? 1 : -1, std::memory_order_release);
         t_tail = ms_since(t_start);
-        // the caller's array is pinned for the duration of the call (1.2 ms for 79 MB, hidden here): the copy back then runs at the
-        // link rate (55 instead of 37-47 GB/s) and takes no page faults.  Memory that cannot be registered is only touched.
-        if (nvox && hipHostRegister(out_host, nvox, hipHostRegisterDefault) == hipSuccess) {
-            out_pinned = true;
-        } else {
-            (void)hipGetLastError();
-            volatile uint8_t* o = out_host;
-            for (size_t i = 0; i < nvox; i += 4096) o[i] = 0;
-            if (nvox) o[nvox - 1] = 0;
-        }
+        // (Pinning the caller's array here with hipHostRegister makes the copy back 0.4 ms faster -- tools/host_pin_probe.py -- but an
+        // array from the malloc heap shares its first and last page with other objects and with the runtime's own cache of pinned
+        // user ranges; one whole-suite run aborted inside the next model load after such a registration, so the pages are touched.)
+        volatile uint8_t* o = out_host;
+        for (size_t i = 0; i < nvox; i += 4096) o[i] = 0;
+        if (nvox) o[nvox - 1] = 0;
         t_touch = ms_since(t_start);
     });
     hipError_t err = hipMemcpyAsync(e->app.vol.p, vol_host, (size_t)std::min(n, head) * slice * esz, hipMemcpyHostToDevice, e->stream);
@@ -388,15 +383,14 @@ int lm_apply_host(lm_engine* e, int slot, int fill_slot, const void* vol_host, i
         back = hipMemcpyAsync(out_host, e->app.out.p, nvox, hipMemcpyDeviceToHost, e->stream);
         if (back == hipSuccess) back = hipStreamSynchronize(e->stream);
     }
-    if (out_pinned) (void)hipHostUnregister(out_host);
     if (rc != LM_OK) return rc;
     if (back != hipSuccess) {
         set_error("lm_apply_host: device-to-host copy failed: %s", hipGetErrorString(back));
         return LM_ERR_DEVICE;
     }
     if (timing)
-        fprintf(stderr, "lm_apply_host: head H2D returned %.2f ms | helper: tail enqueued %.2f, output %s %.2f | hot path returned %.2f | joined %.2f | D2H done %.2f ms\n", t_head,
-                t_tail, out_pinned ? "pinned" : "touched", t_touch, t_apply, t_join, ms_since(t_start));
+        fprintf(stderr, "lm_apply_host: head H2D returned %.2f ms | helper: tail enqueued %.2f, pages touched %.2f | hot path returned %.2f | joined %.2f | D2H done %.2f ms\n", t_head,
+                t_tail, t_touch, t_apply, t_join, ms_since(t_start));
     return LM_OK;
 }
 

@@ -46,6 +46,19 @@ def check_reshape(eng):
     for i in range(int(g["n_rs"])):
         out = eng.reshape_mask(g[f"rs{i}_mask"], g[f"rs{i}_box"], tuple(int(x) for x in g[f"rs{i}_osz"]))[0]
         assert np.array_equal(out, g[f"rs{i}_out"]), i
+    # stacks of slices with a box each, against the oracle: the row-tiled kernel (width a multiple of 4; 100 rows = 6 full row
+    # groups + one of 4) and the voxel-wise one
+    rng = np.random.default_rng(17)
+    for osz in ((100, 132), (50, 90)):
+        masks = rng.integers(0, 4, size=(5, 64, 64)).astype(np.uint8)
+        boxes = []
+        for _ in range(5):
+            r0, c0 = int(rng.integers(0, osz[0] // 2)), int(rng.integers(0, osz[1] // 2))
+            boxes.append([r0, c0, int(rng.integers(r0 + 2, osz[0] + 1)), int(rng.integers(c0 + 2, osz[1] + 1))])
+        boxes[0] = [0, 0, osz[0], osz[1]]
+        out = eng.reshape_mask(masks, np.asarray(boxes), osz)
+        for i in range(5):
+            assert np.array_equal(out[i], po.reshape_mask(masks[i], boxes[i], osz)), (osz, i, boxes[i])
     return int(g["n_rs"])
 
 
