@@ -1505,6 +1505,188 @@ __global__ __launch_bounds__(256) void upsample2x_h3_kernel(UpsampleParams p) {
     *reinterpret_cast<uint4*>(dst + 16) = lo;
 }
 
+// ---------------------------------------------------------------------------------------------
+// 1x1 conv (at LOW resolution, resunet.py:144-155 commuted, see nn_engine.hip) + bilinear x2 in ONE kernel: the low-resolution
+// result never goes to memory.  Measured motive (tools/bw_tail_ablation.py, profiles/r03i_*): the bandwidth-bound kernels are NOT
+// hidden by the second forward lane -- under the power budget every byte moved costs matrix clock -- the 1x1 convs and the
+// upsamples were 5.2 ms of a 68 ms forward.
+// A work item is 64 output channels x a tile of 8 x 16 low-resolution cells: it computes the 1x1 conv on the 9 x 17 pixels
+// r0..r0+8, c0..c0+16 (clamped to the image: one row/column of overlap with the next tile; the pixels of a 1x1 conv are
+// independent, so any list of <= 160 of them fills the five N-tiles), rounds through the split format exactly as the stand-alone
+// 1x1 kernel does, parks the tile in LDS in the tensor's own pixel layout, and every cell (i, j) then writes the 2 x 2 output pixels
+// (2i+1..2i+2, 2j+1..2j+2) that depend on the pixels i..i+1, j..j+1 only (plus row/column 0 of the image from the cells of its
+// first row/column) with upsample2x_h3_kernel's own expression: bit-identical to the two kernels it replaces.
+// Five waves, wave = N-tile (both M-tiles of 32 channels).  Operands are staged through LDS 32 input channels at a time with
+// whole-line loads (8 lanes per pixel: a first version that loaded the fragments straight from global memory spent 2.5x the
+// time of the stand-alone 1x1 kernel in the texture addresser: 16 bytes per lane from 32 different lines per instruction); one
+// barrier per stage, the next stage's loads in flight under the matrix instructions.  64 KB of LDS: two workgroups per CU, one
+// in its memory-bound main loop while the other computes and stores its outputs.
+constexpr int UP_TR = 8, UP_TC = 16, UP_NPX = 160, UP_NVALID = (UP_TR + 1) * (UP_TC + 1), UP_PW1 = UP_TC + 1;
+constexpr int UP_PSTR = 272;   // parked tile: 256 B of split data + 16 B pad per pixel
+constexpr int UP_SSTR = 144;   // staged operands: 128 B (32 channels) + 16 B pad per pixel / weight row (conflict-free b128 reads)
+constexpr int UP_STAGE_BYTES = (UP_NPX + 64) * UP_SSTR;
+constexpr int UP_THREADS = 320;
+constexpr int UP_PIECES = (UP_NPX + 64) * 8;                        // 16-byte pieces of a stage
+constexpr int UP_PPT = (UP_PIECES + UP_THREADS - 1) / UP_THREADS;   // per thread
+static_assert(UP_NVALID <= UP_NPX && 2 * UP_STAGE_BYTES >= UP_NPX * UP_PSTR, "the parked tile reuses the operand buffers");
+
+__global__ __launch_bounds__(UP_THREADS) void conv1x1_up2x_h3_kernel(ConvParamsH3 p) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * UP_STAGE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = lm_uniform(tid >> 6);
+    const int li = lane & 31, kb = lane >> 5;
+    const int h = p.H, w = p.W;  // low resolution
+    const int n_ct = p.Cout >> 6, tiles_x = (w + UP_TC - 1) / UP_TC, tiles_y = (h + UP_TR - 1) / UP_TR;
+    int it = blockIdx.x;
+    const int ct = it % n_ct;
+    it /= n_ct;
+    const int tx = it % tiles_x;
+    it /= tiles_x;
+    const int ty = it % tiles_y, b = it / tiles_y;
+    const int r0 = ty * UP_TR, c0 = tx * UP_TC, n0 = ct * 64;
+#ifdef LM_LAB_HOOKS  // tools/up2x_lab.py: p.head_C (unused here) selects a timing variant: 1 = no main loop, 2 = no output phase
+    const int lab_variant = p.head_C;
+#else
+    constexpr int lab_variant = 0;
+#endif
+
+    // ---- staging geometry: piece = (row of the stage image, 16-byte slot 0..7); rows 0..159 pixels, 160..223 weight rows
+    const char* gsrc[UP_PPT];
+    int ldst[UP_PPT];
+#pragma unroll
+    for (int k = 0; k < UP_PPT; ++k) {
+        const int piece = tid + k * UP_THREADS;
+        const int row = piece >> 3, slot = piece & 7;
+        ldst[k] = piece < UP_PIECES ? row * UP_SSTR + slot * 16 : -1;
+        if (row < UP_NPX) {
+            const int n = row < UP_NVALID ? row : UP_NVALID - 1;  // padding pixels hold something valid that nobody reads
+            const int pr = n / UP_PW1, pc = n - pr * UP_PW1;
+            const int r = min(r0 + pr, h - 1), c = min(c0 + pc, w - 1);
+            gsrc[k] = p.in + ((((size_t)b * h + r) * w + c) * p.in_cstride + p.in_coff) * 4 + slot * 16;
+        } else {
+            const int co = min(row - UP_NPX, 63);
+            gsrc[k] = p.w + ((size_t)(n0 + co) * p.Cin) * 4 + slot * 16;
+        }
+    }
+    // ---- 1x1 conv: D[cout][pixel] += W[cout][k] * A[k][pixel], three products per 16-channel chunk in the order of conv_igemm_h3p
+    lm_f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[m][k] = 0.f;
+    const int nstages = lab_variant == 1 ? 0 : p.Cin >> 5;
+    // (six named registers: as an array or a struct returned from a lambda the compiler kept the staged pieces in scratch memory)
+    static_assert(UP_PPT == 6, "UP_FOR_PIECES lists the pieces by hand");
+#define UP_FOR_PIECES(X) X(0) X(1) X(2) X(3) X(4) X(5)
+#define UP_DECL(k) uint4 piece##k;
+#define UP_FETCH(k) piece##k = *reinterpret_cast<const uint4*>(gsrc[k] + fetch_off);  // (pieces past the end re-read weight row 63)
+#define UP_PUT(k) \
+    if (ldst[k] >= 0) *reinterpret_cast<uint4*>(buf + ldst[k]) = piece##k;
+    UP_FOR_PIECES(UP_DECL)
+    size_t fetch_off = 0;
+    UP_FOR_PIECES(UP_FETCH)
+    const int a_off = (wave * 32 + li) * UP_SSTR + kb * 32, w_off = (UP_NPX + li) * UP_SSTR + kb * 32;
+    for (int s = 0; s < nstages; ++s) {
+        char* buf = lds + (s & 1) * UP_STAGE_BYTES;
+        UP_FOR_PIECES(UP_PUT)
+        __syncthreads();  // (the buffer written at the top of stage s+1 was last read in stage s-1: every thread is past that here)
+        fetch_off = (size_t)min(s + 1, nstages - 1) * 128;  // (the last stage fetches itself again: no branch around the loads)
+        UP_FOR_PIECES(UP_FETCH)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {  // the two 16-channel chunks of the stage
+            lm_h16x8 ah, al, wh, wl;
+            memcpy(&ah, buf + a_off + c * 64, 16);
+            memcpy(&al, buf + a_off + c * 64 + 16, 16);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                memcpy(&wh, buf + w_off + m * 32 * UP_SSTR + c * 64, 16);
+                memcpy(&wl, buf + w_off + m * 32 * UP_SSTR + c * 64 + 16, 16);
+                acc[m] = lm_mfma_f32_32x32x16_f16(wh, ah, acc[m]);
+                acc[m] = lm_mfma_f32_32x32x16_f16(wh, al, acc[m]);
+                acc[m] = lm_mfma_f32_32x32x16_f16(wl, ah, acc[m]);
+            }
+        }
+    }
+#undef UP_FOR_PIECES
+#undef UP_DECL
+#undef UP_FETCH
+#undef UP_PUT
+    __syncthreads();  // the parked tile overwrites both operand buffers
+    // ---- bias, split, park the tile: accumulator register 4 g4 + k of lane (li, kb) is channel 32 m + 8 g4 + 4 kb + k of pixel li
+    char* stage = lds;
+    unsigned gmax = 0u;
+    {
+        const int n = wave * 32 + li;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int cl = 32 * m + 8 * g4 + 4 * kb;
+                const float4 bias = *reinterpret_cast<const float4*>(p.bias + n0 + cl);
+                const float v0 = fmaf(acc[m][4 * g4 + 0], p.acc_scale, bias.x), v1 = fmaf(acc[m][4 * g4 + 1], p.acc_scale, bias.y),
+                            v2 = fmaf(acc[m][4 * g4 + 2], p.acc_scale, bias.z), v3 = fmaf(acc[m][4 * g4 + 3], p.acc_scale, bias.w);
+                uint2 ph, plo;
+                lm_split4(v0, v1, v2, v3, &ph, &plo);
+                if (n < UP_NVALID) gmax = lm_pk_absmax_u16(lm_pk_absmax_u16(gmax, ph.x), ph.y);
+                char* d = stage + n * UP_PSTR + (cl >> 3) * 32 + (cl & 7) * 2;
+                *reinterpret_cast<uint2*>(d) = ph;
+                *reinterpret_cast<uint2*>(d + 16) = plo;
+            }
+    }
+    if (p.range_flag != nullptr && lm_pk_out_of_f16_guard(gmax)) atomicOr(p.range_flag, 1u);
+    __syncthreads();
+    // ---- bilinear x2 (align_corners=False): unit = (cell, 8-channel group), group fastest
+    const int H2 = 2 * h, W2 = 2 * w;
+    for (int u = tid; u < (lab_variant == 2 ? 0 : UP_TR * UP_TC * 8); u += UP_THREADS) {
+        const int g = u & 7, cell = u >> 3;
+        const int i = cell / UP_TC, j = cell - i * UP_TC;
+        const int gi = r0 + i, gj = c0 + j;
+        if (gi >= h || gj >= w) continue;
+        float a[2][2][8];  // [row i, i+1][column j, j+1] (clamped by the loader)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) load_group(stage + ((i + dy) * UP_PW1 + (j + dx)) * UP_PSTR + g * 32, a[dy][dx]);
+        // output rows: 2gi+1 (weights .75/.25), 2gi+2 (.25/.75, if it exists), and row 0 from the first image row (1/0 on itself)
+#pragma unroll
+        for (int ys = 0; ys < 3; ++ys) {
+            const int y = ys == 0 ? 2 * gi + 1 : (ys == 1 ? 2 * gi + 2 : 0);
+            if (ys == 1 ? y >= H2 : (ys == 2 && gi != 0)) continue;
+            const float wya = ys == 0 ? 0.75f : (ys == 1 ? 0.25f : 1.f), wyb = ys == 0 ? 0.25f : (ys == 1 ? 0.75f : 0.f);
+            const int rb = ys == 2 ? 0 : 1;  // the "yb" row of the expression: the row itself for output row 0
+#pragma unroll
+            for (int xs = 0; xs < 3; ++xs) {
+                const int x = xs == 0 ? 2 * gj + 1 : (xs == 1 ? 2 * gj + 2 : 0);
+                if (xs == 1 ? x >= W2 : (xs == 2 && gj != 0)) continue;
+                const float wxa = xs == 0 ? 0.75f : (xs == 1 ? 0.25f : 1.f), wxb = xs == 0 ? 0.25f : (xs == 1 ? 0.75f : 0.f);
+                const int cb = xs == 2 ? 0 : 1;
+                float o[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] = wya * (wxa * a[0][0][k] + wxb * a[0][cb][k]) + wyb * (wxa * a[rb][0][k] + wxb * a[rb][cb][k]);
+                char* dst = p.out + ((((size_t)b * H2 + y) * W2 + x) * p.out_cstride + p.out_coff + n0) * 4 + (size_t)g * 32;
+                uint2 h0, l0, h1, l1;
+                lm_split4(o[0], o[1], o[2], o[3], &h0, &l0);
+                lm_split4(o[4], o[5], o[6], o[7], &h1, &l1);
+                const uint4 hi = {h0.x, h0.y, h1.x, h1.y}, lo = {l0.x, l0.y, l1.x, l1.y};
+                *reinterpret_cast<uint4*>(dst) = hi;
+                *reinterpret_cast<uint4*>(dst + 16) = lo;
+            }
+        }
+    }
+}
+
+bool conv1x1_up2x_h3_ok(const ConvParamsH3& p) {
+    return p.bn_s == nullptr && p.border_corr == nullptr && p.pool == nullptr && p.head_labels == nullptr && p.Cout % 64 == 0 && p.Cin % 64 == 0 &&
+           (p.in_cstride & 7) == 0 && (p.in_coff & 7) == 0 && (p.out_cstride & 7) == 0 && (p.out_coff & 7) == 0 && p.H >= 2 && p.W >= 2;
+}
+
+// p describes the 1x1 conv at LOW resolution (H, W = input size); p.out is the [B][2H][2W][out_cstride] tensor
+hipError_t launch_conv1x1_up2x_h3(const ConvParamsH3& p, hipStream_t stream) {
+    if (!conv1x1_up2x_h3_ok(p)) return hipErrorInvalidValue;
+    const unsigned items = (unsigned)p.B * ((p.H + UP_TR - 1) / UP_TR) * ((p.W + UP_TC - 1) / UP_TC) * ((unsigned)p.Cout / 64);
+    LM_LAUNCH(conv1x1_up2x_h3_kernel, dim3(items), dim3(UP_THREADS), 0, stream, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_upsample2x_h3(const UpsampleParams& p, hipStream_t stream) {
     if ((p.C & 7) || (p.out_cstride & 7) || (p.out_coff & 7)) return hipErrorInvalidValue;
     const unsigned row_elems = (unsigned)(2 * p.w) * (unsigned)(p.C >> 3);

@@ -22,7 +22,7 @@ for lanes in (2, 1):
     eng.set_streams(lanes)
     for rep in range(2):
         row = []
-        for mask in (0, 1, 2, 4, 6, 7, 0):
+        for mask in (0, 4, 6, 0):  # 1 and 2 alone would feed stale buffers of OTHER layers to their consumers (the workspaces are reused)
             os.environ["LM_ABL_SKIP"] = str(mask)
             if mask == 0: f(); eng.sync()  # refresh the buffers with a complete forward
             row.append((mask, timed()))
