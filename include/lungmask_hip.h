@@ -63,6 +63,25 @@ int lm_engine_sync(lm_engine* e);
  * / waiting for this stream instead of synchronising the device.  NULL for a NULL engine. */
 void* lm_engine_stream(lm_engine* e);
 
+/* ---- one rank per engine: RCCL communicator behind the C ABI --------------------------------------
+ * The reference has no multi-GPU form; the slice-sharded pipeline (lungmask_amd/pipeline.py) needs exactly one
+ * collective -- an equal-size all-gather of device buffers (label shards, slab-protocol planes/tables, the result) -- and with
+ * these entry points it needs nothing else from the host's GPU stack.  RCCL is bound at run time (dlopen; torch's copy when
+ * one is already mapped); a world of one initialised WITHOUT an id involves no library at all (its all-gather is a copy), with
+ * an id it is a real RCCL communicator of one rank.
+ *   rank 0: lm_dist_unique_id(id);  -> hand the 128 bytes to every rank by any side channel (a TCP store, a file, MPI)
+ *   every rank: lm_dist_init(e, rank, world, id);   ...   lm_dist_all_gather(e, send, recv, bytes);   ...   lm_dist_destroy(e);
+ * lm_dist_all_gather: recv_dev holds world * bytes, rank r's contribution at r * bytes (send_dev may be that very slot: in
+ * place).  It is ENQUEUED on the engine's stream (lm_engine_stream): ordered after the engine's earlier kernels and before its
+ * later ones, the host does not wait. */
+#define LM_DIST_ID_BYTES 128
+int lm_dist_unique_id(uint8_t* id_out /* [LM_DIST_ID_BYTES] */);
+int lm_dist_init(lm_engine* e, int rank, int world, const uint8_t* id /* [LM_DIST_ID_BYTES]; NULL allowed when world == 1 */);
+int lm_dist_rank(lm_engine* e);  /* < 0 without a communicator */
+int lm_dist_world(lm_engine* e); /* < 0 without a communicator */
+int lm_dist_all_gather(lm_engine* e, const void* send_dev, void* recv_dev, size_t bytes);
+int lm_dist_destroy(lm_engine* e);
+
 /* ---- device memory helpers (so a binding needs no other GPU runtime) ---------- */
 int lm_dev_alloc(lm_engine* e, void** dev_ptr, size_t bytes);
 int lm_dev_free(lm_engine* e, void* dev_ptr);

@@ -65,6 +65,13 @@ class Library:
         if hasattr(L, "lm_engine_stream"):
             L.lm_engine_stream.argtypes = [C.c_void_p]
             L.lm_engine_stream.restype = C.c_void_p
+        if hasattr(L, "lm_dist_init"):
+            L.lm_dist_unique_id.argtypes = [C.c_void_p]
+            L.lm_dist_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+            L.lm_dist_rank.argtypes = [C.c_void_p]
+            L.lm_dist_world.argtypes = [C.c_void_p]
+            L.lm_dist_all_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+            L.lm_dist_destroy.argtypes = [C.c_void_p]
         if hasattr(L, "lm_model_precision"):  # (absent from older builds that tools/ab_forward.py may load for comparison)
             L.lm_model_precision.argtypes = [C.c_void_p, C.c_int]
         L.lm_forward_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -200,6 +207,26 @@ class Engine:
     def stream_handle(self) -> int:
         """hipStream_t of the engine as an integer (0 under emulation): see lm_engine_stream in include/lungmask_hip.h."""
         return int(self.L.lib.lm_engine_stream(self.h) or 0)
+
+    # -- one rank per engine: the RCCL communicator behind the C ABI (include/lungmask_hip.h: lm_dist_*)
+    def dist_unique_id(self) -> bytes:
+        """128 opaque bytes that rank 0 creates and every rank passes to dist_init (ncclUniqueId)."""
+        buf = (C.c_uint8 * 128)()
+        self.L.check(self.L.lib.lm_dist_unique_id(buf), "lm_dist_unique_id")
+        return bytes(buf)
+
+    def dist_init(self, rank: int, world: int, unique_id: Optional[bytes] = None):
+        if unique_id is not None and len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of dist_unique_id()")
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id) if unique_id is not None else None
+        self.L.check(self.L.lib.lm_dist_init(self.h, int(rank), int(world), buf), "lm_dist_init")
+
+    def dist_all_gather(self, send_ptr: int, recv_ptr: int, nbytes: int):
+        """Equal-size all-gather of device buffers, enqueued on the engine's stream (recv holds world * nbytes)."""
+        self.L.check(self.L.lib.lm_dist_all_gather(self.h, send_ptr, recv_ptr, int(nbytes)), "lm_dist_all_gather")
+
+    def dist_destroy(self):
+        self.L.check(self.L.lib.lm_dist_destroy(self.h), "lm_dist_destroy")
 
     def n_classes(self, slot: int) -> int:
         return self.L.check(self.L.lib.lm_model_classes(self.h, slot), "lm_model_classes")

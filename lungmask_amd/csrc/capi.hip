@@ -57,6 +57,7 @@ int lm_engine_create(lm_engine** out, int device_id) {
 
 void lm_engine_destroy(lm_engine* e) {
     if (!e) return;
+    (void)lm_dist_destroy(e);
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     e->prof.release();

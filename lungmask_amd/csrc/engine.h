@@ -182,6 +182,9 @@ struct lm_engine {
     std::atomic<int> tail_enqueued{0};
     unsigned* range_flag = nullptr;       // device word of the f16 range guard (ConvParamsH3::range_flag)
     unsigned* range_flag_host = nullptr;  // pinned copy
+    // lm_dist_* (dist_rccl.hip): RCCL communicator of this engine's rank; world 0 = none, world 1 = no library involved
+    void* dist_comm = nullptr;
+    int dist_rank = 0, dist_world = 0;
 };
 
 namespace lm {

@@ -17,8 +17,9 @@ Each rank then un-crops its own slices and a final all-gather assembles the [n,h
 result on every rank (79 MB per rank at 300 slices/rank; xGMI is point-to-point and fully
 connected inside a node, so it is single-step and per-link bound, well under a millisecond).
 
-All buffers are torch tensors (device memory + collectives are torch's job here,
-nothing else); the engine receives raw pointers.  On the GPU the engine's own HIP stream
+All buffers are torch tensors (device memory is torch's job here); the engine receives raw pointers.  The collectives come
+either from torch.distributed or -- `NativeDist` -- from the engine's own RCCL communicator behind the C ABI (lm_dist_*), in
+which case torch is a buffer allocator and nothing more.  On the GPU the engine's own HIP stream
 (`lm_engine_stream`) is made torch's current stream for everything in here, so the RCCL
 collectives are ordered against the engine's kernels by stream dependencies (torch's
 process group waits for the current stream before a collective and lets it wait for the
@@ -44,8 +45,43 @@ def shard_bounds(n: int, world: int) -> List[int]:
     return b
 
 
+class NativeDist:
+    """The `dist` argument of ShardedPipeline WITHOUT torch.distributed: the engine's own RCCL communicator behind the C ABI
+    (include/lungmask_hip.h: lm_dist_*).  The one collective of the pipeline, an equal-size all-gather of device buffers, is
+    enqueued on the engine's stream.  `unique_id`: the 128 bytes rank 0 got from `engine.dist_unique_id()`, handed to the other
+    ranks by any side channel (`exchange_id` uses a torch.distributed Store; a file or MPI do as well).  A world of one without
+    an id involves no library."""
+
+    def __init__(self, engine, rank: int, world: int, unique_id: bytes = None):
+        engine.dist_init(rank, world, unique_id)
+        self.e, self.rank, self.world = engine, int(rank), int(world)
+
+    @staticmethod
+    def exchange_id(engine, rank: int, store, key: str = "lungmask_amd/dist_id") -> bytes:
+        """Rank 0 creates the id and publishes it in `store` (e.g. torch.distributed.TCPStore); the others read it."""
+        if rank == 0:
+            uid = engine.dist_unique_id()
+            store.set(key, uid)
+            return uid
+        return bytes(store.get(key))
+
+    def get_world_size(self) -> int:
+        return self.world
+
+    def get_rank(self) -> int:
+        return self.rank
+
+    def all_gather_into_tensor(self, out: torch.Tensor, mine: torch.Tensor):
+        nbytes = mine.numel() * mine.element_size()
+        assert out.is_contiguous() and mine.is_contiguous() and out.numel() * out.element_size() == self.world * nbytes
+        self.e.dist_all_gather(mine.data_ptr(), out.data_ptr(), nbytes)
+
+    def destroy(self):
+        self.e.dist_destroy()
+
+
 class ShardedPipeline:
-    """engine: lungmask_amd._native.Engine; dist: the torch.distributed module (initialised) or None;
+    """engine: lungmask_amd._native.Engine; dist: the torch.distributed module (initialised), a NativeDist, or None;
     device: torch device that matches the engine's memory space ('cuda:<i>' or 'cpu' under emulation)."""
 
     def __init__(self, engine, slot: int = 0, batch_size: int = 20, volume_postprocessing: bool = True,

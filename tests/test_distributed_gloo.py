@@ -122,3 +122,43 @@ def test_multi_rank_gloo_assemble_and_slab_protocol(tmp_path, world, n_total):
             assert np.array_equal(np.load(tmp_path / f"asm{sharded}_{r}.npy"), expect), (sharded, r)
     got = np.concatenate([np.load(tmp_path / f"slab{r}.npy") for r in range(world)])
     assert np.array_equal(got, po.postprocessing(lab.copy(), spare=[4]))
+
+
+def test_native_dist_world_of_one_and_argument_checks(emu_engine):
+    """`NativeDist` (the engine's own communicator behind the C ABI, lm_dist_*) as the `dist` of the pipeline: a world of one
+    without an id involves no RCCL (so it runs under emulation); the exchange protocol, the gathers and the un-crop give the
+    single-engine result.  Misuse is refused with an error, not a crash.  (The real RCCL communicator runs in the GPU suite.)"""
+    from lungmask_amd import _native as nat
+    from lungmask_amd.pipeline import NativeDist, ShardedPipeline
+    from oracle import prepost_oracle as po
+    from oracle.make_golden import random_blobs
+
+    with pytest.raises(nat.LMError):
+        emu_engine.dist_all_gather(0, 0, 16)  # no communicator yet
+    with pytest.raises(nat.LMError):
+        emu_engine.dist_init(2, 2, b"\0" * 128)  # rank out of range
+    with pytest.raises(nat.LMError):
+        emu_engine.dist_init(0, 2, None)  # a world of two needs the id
+    nd = NativeDist(emu_engine, 0, 1)
+    try:
+        with pytest.raises(nat.LMError):
+            emu_engine.dist_init(0, 1)  # already initialised
+        assert (nd.get_rank(), nd.get_world_size()) == (0, 1)
+        a = torch.arange(40, dtype=torch.int32)
+        out = torch.zeros(40, dtype=torch.int32)
+        nd.all_gather_into_tensor(out, a)
+        assert torch.equal(out, a)
+        n_total = 5
+        lab = random_blobs(np.random.default_rng(5), (n_total, 32, 32), 3, 9, 0.3)
+        boxes = np.asarray([[1 + i, 2, 60 + i, 70] for i in range(n_total)], dtype=np.int32)
+        expect = np.asarray([po.reshape_mask(p, b, (96, 80)) for p, b in zip(po.postprocessing(lab.copy()), boxes)], dtype=np.uint8)
+        for sharded in (True, False):
+            pipe = ShardedPipeline(emu_engine, resolution=(32, 32), dist=nd, device="cpu", sharded_post=sharded)
+            _, bbox, _, lab_loc = pipe.shard_buffers(n_total)
+            lab_loc[:n_total] = torch.from_numpy(lab)
+            bbox[:n_total] = torch.from_numpy(boxes)
+            assert np.array_equal(pipe.assemble(n_total, 96, 80).numpy(), expect), sharded
+    finally:
+        nd.destroy()
+    with pytest.raises(nat.LMError):
+        emu_engine.dist_all_gather(0, 0, 16)

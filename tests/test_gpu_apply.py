@@ -217,6 +217,36 @@ def test_sharded_pipeline_over_rccl_process_group_of_one(gpu_engine):
         dist.destroy_process_group()
 
 
+def test_sharded_pipeline_over_the_engines_own_rccl_communicator(gpu_engine):
+    """The same with the collectives behind the C ABI (lm_dist_*, NativeDist) instead of torch.distributed: a real RCCL
+    communicator of one rank (an id is passed, so the library IS used: ncclGetUniqueId, ncclCommInitRank, ncclAllGather on the
+    engine's stream, ncclCommDestroy), both post-processing forms, in-place gathers; then the no-library form of a world of one."""
+    from lungmask_amd.pipeline import NativeDist, ShardedPipeline
+
+    sd = uo.synthetic_state_dict(3)
+    gpu_engine.load_state_dict(0, sd)
+    vol = po.phantom(25, 512, 512, seed=12)
+    expect = gpu_engine.apply(0, vol, batch_size=20)
+    vt = torch.from_numpy(vol).to("cuda:0")
+    uid = gpu_engine.dist_unique_id()
+    assert len(uid) == 128 and any(uid)
+    for unique_id in (uid, None):
+        nd = NativeDist(gpu_engine, 0, 1, unique_id)
+        try:
+            a = torch.arange(1000, dtype=torch.int32, device="cuda:0")
+            out = torch.zeros_like(a)
+            with torch.cuda.stream(torch.cuda.ExternalStream(gpu_engine.stream_handle(), device=torch.device("cuda:0"))):
+                nd.all_gather_into_tensor(out, a)
+            gpu_engine.sync()
+            assert torch.equal(out, a)
+            for sharded_post in (True, False):
+                pipe = ShardedPipeline(gpu_engine, slot=0, batch_size=20, dist=nd, device="cuda:0", sharded_post=sharded_post)
+                got = pipe.apply_shard(vt, len(vol)).cpu().numpy()
+                assert np.array_equal(got, expect), (unique_id is not None, sharded_post)
+        finally:
+            nd.destroy()
+
+
 def test_two_ranks_on_one_gpu_over_rccl(gpu_engine):
     """the real RCCL transport has only ever met a world of one, where every all-gather is a copy.  Two ranks
     sharing cuda:0 would let in-place views, ragged shards and the stream ordering between the engine and the collectives meet
