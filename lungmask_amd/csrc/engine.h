@@ -195,6 +195,8 @@ int forward_batches(lm_engine* e, int slot, const float* x, int n, int H, int W,
 // The two above + the f16 range guard: waits for the forward, and when a split-f16 forward reported activations beyond the f16
 // range, pins the model to the exact-fp32 kernels and runs the forward again.  What the C ABI and lm_apply call.
 int forward_guarded(lm_engine* e, int slot, const float* x, int n, int H, int W, int batch, uint8_t* labels, float* logp);
+// the check alone, for callers that enqueue several forward_batches first (post_engine.hip: inference)
+int forward_range_check(lm_engine* e, int slot, bool* tripped);
 int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spare, int n_spare, int skip_below);
 struct BoundaryRec;
 void replay_merge(int R, const int* area, const uint8_t* lv, const BoundaryRec* recs, size_t nrecs, const std::vector<int>& spare, int skip_below,

@@ -623,28 +623,39 @@ int forward_batches(lm_engine* e, int slot, const float* x, int n, int H, int W,
 }
 
 // ------------------------------------------------------------------------------ f16 range guard
+// Reads the range flag back behind everything enqueued on the main stream (one 4-byte copy + a stream sync).  When it is set the
+// model is pinned to the exact-fp32 kernels and *tripped is true: the caller runs its forward passes again.
+int forward_range_check(lm_engine* e, int slot, bool* tripped) {
+    *tripped = false;
+    Model& md = e->models[slot];
+    const bool h3 = e->precision == 1 && !md.force_f32;
+    if (!h3 || e->range_flag == nullptr) return LM_OK;
+    LM_HIP(hipMemcpyAsync(e->range_flag_host, e->range_flag, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
+    LM_HIP(hipStreamSynchronize(e->stream));
+    if (*e->range_flag_host == 0) return LM_OK;
+    LM_HIP(hipMemsetAsync(e->range_flag, 0, sizeof(unsigned), e->stream));
+    *e->range_flag_host = 0;
+    md.force_f32 = true;
+    *tripped = true;
+    fprintf(stderr,
+            "lungmask_hip: activations of model slot %d left the f16 range (|v| >= 2^15): its forward passes run on the exact-fp32 "
+            "matrix kernels from now on (about 4x slower, same results as the reference)\n",
+            slot);
+    return LM_OK;
+}
+
 int forward_guarded(lm_engine* e, int slot, const float* x, int n, int H, int W, int batch, uint8_t* labels, float* logp) {
     if (slot < 0 || slot >= 4 || !e->models[slot].loaded) {
         set_error("model slot %d is empty", slot);
         return LM_ERR_NOMODEL;
     }
-    Model& md = e->models[slot];
     for (int attempt = 0; attempt < 2; ++attempt) {
-        const bool h3 = e->precision == 1 && !md.force_f32;
         if (logp != nullptr || batch <= 0) LM_TRY(forward(e, slot, x, n, H, W, labels, logp));
         else LM_TRY(forward_batches(e, slot, x, n, H, W, batch, labels));
-        if (!h3 || e->range_flag == nullptr) return LM_OK;
-        // the lanes have been joined into the main stream: one 4-byte read-back behind them
-        LM_HIP(hipMemcpyAsync(e->range_flag_host, e->range_flag, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
-        LM_HIP(hipStreamSynchronize(e->stream));
-        if (*e->range_flag_host == 0) return LM_OK;
-        LM_HIP(hipMemsetAsync(e->range_flag, 0, sizeof(unsigned), e->stream));
-        *e->range_flag_host = 0;
-        md.force_f32 = true;
-        fprintf(stderr,
-                "lungmask_hip: activations of model slot %d left the f16 range (|v| >= 2^15): its forward passes run on the exact-fp32 "
-                "matrix kernels from now on (about 4x slower, same results as the reference)\n",
-                slot);
+        // (the lanes have been joined into the main stream)
+        bool tripped = false;
+        LM_TRY(forward_range_check(e, slot, &tripped));
+        if (!tripped) return LM_OK;
     }
     return LM_OK;
 }

@@ -238,32 +238,26 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
         ProfScope ps(e, "post_component_max", (double)nvox * 9);
         LM_K(component_max(parent, mapped, ids /* reused: area per root */, best_dev, nvox, s));
     }
+    // bounding boxes of the kept components: the hole fill of a label only has to look inside its box (post_kernels.h: Box).  The
+    // roots to keep are derived from `best` on the device, so areas and boxes reach the host in one round trip.
     unsigned long long best[256];
-    LM_HIP(hipMemcpyAsync(best, best_dev, sizeof best, hipMemcpyDeviceToHost, s));
-    LM_HIP(hipStreamSynchronize(s));
-    uint8_t* out = ws.out.as<uint8_t>();
-    LM_HIP(hipMemsetAsync(out, 0, nvox, s));
-    // bounding boxes of the kept components: the hole fill of a label only has to look inside its box (post_kernels.h: Box)
     int keep_roots[256], bbox[256 * 6];
-    bool any = false;
-    for (int label = 0; label < 256; ++label) {
-        keep_roots[label] = (label && best[label]) ? (int)(unsigned)(best[label] & 0xffffffffull) : -1;
-        any = any || keep_roots[label] >= 0;
-        for (int k = 0; k < 6; ++k) bbox[6 * label + k] = k < 3 ? 0x7fffffff : -1;
-    }
-    if (any && N > 1) {
+    if (N > 1) {
         LM_TRY(ws.bbox.reserve((256 + 256 * 6) * sizeof(int)));
         int* kr_dev = ws.bbox.as<int>();
         int* bbox_dev = kr_dev + 256;
-        LM_HIP(hipMemcpyAsync(kr_dev, keep_roots, sizeof keep_roots, hipMemcpyHostToDevice, s));
-        LM_HIP(hipMemcpyAsync(bbox_dev, bbox, sizeof bbox, hipMemcpyHostToDevice, s));
+        LM_K(keep_roots_init(best_dev, kr_dev, bbox_dev, s));
         {
             ProfScope ps(e, "post_component_bbox", (double)nvox * 5);
             LM_K(component_bboxes(parent, mapped, kr_dev, bbox_dev, d, s));
         }
         LM_HIP(hipMemcpyAsync(bbox, bbox_dev, sizeof bbox, hipMemcpyDeviceToHost, s));
-        LM_HIP(hipStreamSynchronize(s));
     }
+    LM_HIP(hipMemcpyAsync(best, best_dev, sizeof best, hipMemcpyDeviceToHost, s));
+    LM_HIP(hipStreamSynchronize(s));
+    uint8_t* out = ws.out.as<uint8_t>();
+    LM_HIP(hipMemsetAsync(out, 0, nvox, s));
+    for (int label = 0; label < 256; ++label) keep_roots[label] = (label && best[label]) ? (int)(unsigned)(best[label] & 0xffffffffull) : -1;
     for (int label = 1; label < 256; ++label) {
         if (!best[label]) continue;
         const int keep_root = keep_roots[label];
@@ -307,6 +301,10 @@ namespace {
 int inference(lm_engine* e, int slot, const void* vol, int dtype, int n, int h, int w, int batch, int vol_post, bool have_pre, uint8_t* out) {
     ApplyWorkspace& a = e->app;
     constexpr int R = 256;  // mask.py:166 resolution=[256, 256]
+    if (slot < 0 || slot >= 4 || !e->models[slot].loaded) {
+        set_error("model slot %d is empty", slot);
+        return LM_ERR_NOMODEL;
+    }
     LM_TRY(a.xf.reserve((size_t)n * R * R * 4));
     LM_TRY(a.bbox.reserve((size_t)n * 16));
     LM_TRY(a.labels.reserve((size_t)n * R * R));
@@ -338,7 +336,15 @@ int inference(lm_engine* e, int slot, const void* vol, int dtype, int n, int h, 
                 LM_K(launch_resample_norm(rp, e->stream));
             }
         }
-        LM_TRY(forward_guarded(e, slot, a.xf.as<float>() + (size_t)s0 * R * R, ns, R, R, batch, a.labels.as<uint8_t>() + (size_t)s0 * R * R, nullptr));  // mask.py:173-187
+        // mask.py:173-187.  The f16 range flag is read back ONCE, behind the last piece: a check per piece would make the host wait
+        // for the head's forward before it could enqueue the tail's
+        LM_TRY(forward_batches(e, slot, a.xf.as<float>() + (size_t)s0 * R * R, ns, R, R, batch, a.labels.as<uint8_t>() + (size_t)s0 * R * R));
+    }
+    {
+        bool tripped = false;
+        LM_TRY(forward_range_check(e, slot, &tripped));
+        if (tripped)  // the model is now pinned to the exact-fp32 kernels: the whole volume again (its pre-processed slices are all there)
+            LM_TRY(forward_guarded(e, slot, a.xf.as<float>(), n, R, R, batch, a.labels.as<uint8_t>(), nullptr));
     }
     if (vol_post) LM_TRY(postprocess(e, a.labels.as<uint8_t>(), n, R, R, nullptr, 0, 3));  // mask.py:191-194
     ReshapeParams rs{a.labels.as<uint8_t>(), a.bbox.as<int>(), out, n, R, R, h, w};  // mask.py:196-202

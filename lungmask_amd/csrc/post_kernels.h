@@ -58,6 +58,9 @@ struct Box {
 };
 // bbox[label] = {zmin, ymin, xmin, zmax, ymax, xmax} (ints; mins preset to INT_MAX, maxs to -1 by the caller) of the voxels whose
 // root is keep_root[lab[v]] (keep_root: 256 ints, -1 for absent labels)
+// keep_root[label] = root of the component `best` (component_max) names for the label, -1 for label 0 / absent labels; bbox preset
+// for component_bboxes -- on the device, so that the areas and the boxes come back to the host in ONE round trip
+hipError_t keep_roots_init(const unsigned long long* best, int* keep_root, int* bbox, hipStream_t s);
 hipError_t component_bboxes(const int* parent, const uint8_t* lab, const int* keep_root, int* bbox, Dims d, hipStream_t s);
 // bg[compact index in the box] = (parent[v] != keep_root)
 hipError_t complement_of_component_box(const int* parent, int keep_root, Dims d, Box box, uint8_t* bg, hipStream_t s);

@@ -870,6 +870,19 @@ hipError_t fill_write(const int* parent, int keep_root, const int* bgparent, con
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void keep_roots_kernel(const unsigned long long* __restrict__ best, int* __restrict__ keep_root, int* __restrict__ bbox) {
+    const int label = threadIdx.x;
+    const unsigned long long b = best[label];
+    keep_root[label] = (label && b) ? (int)(unsigned)(b & 0xffffffffull) : -1;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) bbox[6 * label + k] = k < 3 ? 0x7fffffff : -1;
+}
+
+hipError_t keep_roots_init(const unsigned long long* best, int* keep_root, int* bbox, hipStream_t s) {
+    LM_LAUNCH(keep_roots_kernel, dim3(1), dim3(256), 0, s, best, keep_root, bbox);
+    return hipGetLastError();
+}
+
 hipError_t component_bboxes(const int* parent, const uint8_t* lab, const int* keep_root, int* bbox, Dims d, hipStream_t s) {
     LM_LAUNCH(component_bboxes_kernel, dim3(grid_for(d.nvox(), 64 * 64, 2048)), dim3(TPB), 0, s, parent, lab, keep_root, bbox, d);
     return hipGetLastError();

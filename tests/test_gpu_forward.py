@@ -230,6 +230,17 @@ def test_f16_range_guard_falls_back_to_exact_fp32(gpu_engine):
     gpu_engine.sync()
     assert gpu_engine.model_precision(0) == "f32"
     assert np.array_equal(ld.download(), lab)
+    # and the whole hot path (lm_apply_host: the volume goes through in two pieces, the flag is read back once behind the second;
+    # 7 slices at batch 1 -> head of two batches + tail of five): the same labels as with the model on the exact kernels
+    from oracle import prepost_oracle as po
+
+    vol = po.phantom(7, 512, 512, seed=5)
+    expect = gpu_engine.apply(0, vol, batch_size=1)  # the model is pinned to fp32 at this point
+    gpu_engine.load_state_dict(0, sd)
+    assert gpu_engine.model_precision(0) == "split_f16"
+    got = gpu_engine.apply(0, vol, batch_size=1)
+    assert gpu_engine.model_precision(0) == "f32"
+    assert np.array_equal(got, expect)
     gpu_engine.load_state_dict(0, uo.synthetic_state_dict(3))
     gpu_engine.forward(0, x[:1])
     assert gpu_engine.model_precision(0) == "split_f16"
