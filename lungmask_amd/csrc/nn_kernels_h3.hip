@@ -1507,7 +1507,7 @@ __global__ __launch_bounds__(256) void upsample2x_h3_kernel(UpsampleParams p) {
 
 // ---------------------------------------------------------------------------------------------
 // 1x1 conv (at LOW resolution, resunet.py:144-155 commuted, see nn_engine.hip) + bilinear x2 in ONE kernel: the low-resolution
-// result never goes to memory.  Measured motive (tools/bw_tail_ablation.py, profiles/r03i_*): the bandwidth-bound kernels are NOT
+// result never goes to memory.  Measured motive (tools/bw_tail_ablation.py, profiles/r02zi_*): the bandwidth-bound kernels are NOT
 // hidden by the second forward lane -- under the power budget every byte moved costs matrix clock -- the 1x1 convs and the
 // upsamples were 5.2 ms of a 68 ms forward.
 // A work item is 64 output channels x a tile of 8 x 16 low-resolution cells: it computes the 1x1 conv on the 9 x 17 pixels

@@ -1,7 +1,7 @@
 # Round-end GPU check: full parity suite, smoke, the multi-GPU code path with a world of one, the bench lines of configs 2-4, the host
 # boundary, and the rocprofv3 evidence (kernel stats with one forward lane; add "pmc" as a second argument for the separate PMC
 # passes -- FETCH_SIZE / WRITE_SIZE are only needed again when the conv kernel changes).
-# Usage: gpurun -- 'bash tools/gpu_round_check.sh r03z [pmc]'
+# Usage: gpurun -- 'bash tools/gpu_round_check.sh r02zz [pmc]'
 TAG=${1:-rXX}
 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu_$TAG.log 2>&1; grep -E "passed|failed|error" gpurun_out/pytest_gpu_$TAG.log | tail -3
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -2
