@@ -320,6 +320,8 @@ __global__ __launch_bounds__(1024) void scan_blockcnt_kernel(int* blockcnt, int 
 __global__ __launch_bounds__(TPB) void assign_rank_kernel(const int* __restrict__ P, int* __restrict__ rank, const int* __restrict__ blockoff, size_t nvox) {
     __shared__ int part[TPB];
     const int t = threadIdx.x;
+    // (a volume has ~10^3 roots in ~10^4 blocks: most blocks hold none and have nothing to number; blockoff[nb] is the total)
+    if (blockoff[blockIdx.x + 1] == blockoff[blockIdx.x]) return;
     const size_t base = ((size_t)blockIdx.x * TPB + t) * ITEMS;
     int c = 0;
     for (int i = 0; i < ITEMS; ++i) {
@@ -604,20 +606,36 @@ __global__ __launch_bounds__(TPB) void component_bboxes_kernel(const int* __rest
         sb[i][3] = sb[i][4] = sb[i][5] = -1;
     }
     __syncthreads();
-    const size_t nvox = d.nvox();
-    const size_t HW = (size_t)d.H * d.W;
-    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x) {
-        const int L = lab[v];
-        if (!L || P[v] != kr[L]) continue;
-        int x, y, z;
-            split3(v, d.H, d.W, x, y, z);
-        // (most voxels of a workgroup's contiguous range do not move the extremes: test before the LDS atomic)
-        if (z < sb[L][0]) atomicMin(&sb[L][0], z);
-        if (y < sb[L][1]) atomicMin(&sb[L][1], y);
-        if (x < sb[L][2]) atomicMin(&sb[L][2], x);
-        if (z > sb[L][3]) atomicMax(&sb[L][3], z);
-        if (y > sb[L][4]) atomicMax(&sb[L][4], y);
-        if (x > sb[L][5]) atomicMax(&sb[L][5], x);
+    // One wave per 64-voxel piece of a row: (z, y) are wave-uniform and the x extent of a label inside the piece comes from a
+    // ballot, so ONE lane per (piece, label) touches the LDS table instead of every voxel (the kept components are most of the
+    // foreground: six LDS compares per voxel were the cost of this pass).
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = (blockIdx.x * (unsigned)TPB + threadIdx.x) >> 6, nwaves = (gridDim.x * (unsigned)TPB) >> 6;
+    const unsigned ppr = ((unsigned)d.W + 63u) >> 6;
+    const unsigned npieces = (unsigned)d.N * (unsigned)d.H * ppr;
+    for (unsigned piece = wave; piece < npieces; piece += nwaves) {
+        const unsigned row = piece / ppr;
+        const int z = (int)(row / (unsigned)d.H), y = (int)(row - (unsigned)z * (unsigned)d.H);
+        const int x0 = (int)((piece - row * ppr) << 6), x = x0 + lane;
+        const size_t v = (size_t)row * d.W + x;
+        const int L = x < d.W ? (int)lab[v] : 0;
+        const bool match = L != 0 && P[v] == kr[L];
+        unsigned long long todo = __ballot(match);
+        while (todo) {  // wave-uniform: one round per distinct label among the matching lanes
+            const int src = __ffsll((long long)todo) - 1;
+            const int Ls = __shfl(L, src);
+            const unsigned long long same = __ballot(match && L == Ls);
+            if (lane == src) {
+                const int xa = x0 + __ffsll((long long)same) - 1, xb = x0 + 63 - __clzll((long long)same);
+                if (z < sb[Ls][0]) atomicMin(&sb[Ls][0], z);
+                if (y < sb[Ls][1]) atomicMin(&sb[Ls][1], y);
+                if (xa < sb[Ls][2]) atomicMin(&sb[Ls][2], xa);
+                if (z > sb[Ls][3]) atomicMax(&sb[Ls][3], z);
+                if (y > sb[Ls][4]) atomicMax(&sb[Ls][4], y);
+                if (xb > sb[Ls][5]) atomicMax(&sb[Ls][5], xb);
+            }
+            todo &= ~same;
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 256; i += blockDim.x) {
