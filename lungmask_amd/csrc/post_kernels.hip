@@ -618,8 +618,10 @@ __global__ __launch_bounds__(TPB) void component_bboxes_kernel(const int* __rest
         const int z = (int)(row / (unsigned)d.H), y = (int)(row - (unsigned)z * (unsigned)d.H);
         const int x0 = (int)((piece - row * ppr) << 6), x = x0 + lane;
         const size_t v = (size_t)row * d.W + x;
-        const int L = x < d.W ? (int)lab[v] : 0;
-        const bool match = L != 0 && P[v] == kr[L];
+        const bool in = x < d.W;
+        const int L = in ? (int)lab[v] : 0;
+        const int root = in ? P[v] : -1;  // (unconditional: both loads of the piece in flight together)
+        const bool match = L != 0 && root == kr[L];
         unsigned long long todo = __ballot(match);
         while (todo) {  // wave-uniform: one round per distinct label among the matching lanes
             const int src = __ffsll((long long)todo) - 1;
@@ -902,6 +904,7 @@ hipError_t keep_roots_init(const unsigned long long* best, int* keep_root, int* 
 }
 
 hipError_t component_bboxes(const int* parent, const uint8_t* lab, const int* keep_root, int* bbox, Dims d, hipStream_t s) {
+    // (2048 workgroups: each flushes its LDS table with global atomics on the same few words -- 16384 of them made the pass 5x slower)
     LM_LAUNCH(component_bboxes_kernel, dim3(grid_for(d.nvox(), 64 * 64, 2048)), dim3(TPB), 0, s, parent, lab, keep_root, bbox, d);
     return hipGetLastError();
 }
