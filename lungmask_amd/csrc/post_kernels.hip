@@ -99,7 +99,7 @@ __global__ __launch_bounds__(TPB) void ccl_merge_kernel(const uint8_t* __restric
         const uint8_t L = lab[v];
         if (!L) continue;
         int x, y, z;
-            split3(v, d.H, d.W, x, y, z);
+        split3(v, d.H, d.W, x, y, z);
         const bool left_same = x > 0 && lab[v - 1] == L;
         const bool right_same = x + 1 < d.W && lab[v + 1] == L;
         if (left_same && (v & 63) == 0) unite(P, (int)v, (int)(v - 1));
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(TPB) void boundary_records_kernel(const int* __rest
         if (v < v1) a = ids[v];
         if (a) {
             int x, y, z;
-            split3(v, d.H, d.W, x, y, z);
+        split3(v, d.H, d.W, x, y, z);
             auto add = [&](int b) {
                 if (b == 0 || b == a) return;
 #pragma unroll
@@ -567,10 +567,9 @@ __global__ __launch_bounds__(TPB) void complement_kernel(const int* __restrict__
 
 __global__ __launch_bounds__(TPB) void flag_faces_kernel(const int* __restrict__ BP, int* flags, Dims d) {
     const size_t nvox = d.nvox();
-    const size_t HW = (size_t)d.H * d.W;
     for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x) {
         int x, y, z;
-            split3(v, d.H, d.W, x, y, z);
+        split3(v, d.H, d.W, x, y, z);
         if (x == 0 || y == 0 || z == 0 || x == d.W - 1 || y == d.H - 1 || z == d.N - 1) {
             const int r = BP[v];
             if (r >= 0) flags[r] = 1;
@@ -653,7 +652,6 @@ __global__ __launch_bounds__(TPB) void component_bboxes_kernel(const int* __rest
 
 __global__ __launch_bounds__(TPB) void complement_box_kernel(const int* __restrict__ P, int keep_root, Dims d, Box box, uint8_t* __restrict__ bg) {
     const size_t n = box.d.nvox();
-    const size_t hw = (size_t)box.d.H * box.d.W;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (size_t)gridDim.x * blockDim.x) {
         int x, y, z;
         split3(c, box.d.H, box.d.W, x, y, z);
@@ -665,7 +663,6 @@ __global__ __launch_bounds__(TPB) void complement_box_kernel(const int* __restri
 __global__ __launch_bounds__(TPB) void fill_write_box_kernel(const int* __restrict__ P, int keep_root, const int* __restrict__ BP, const int* __restrict__ flags,
                                                              uint8_t label, uint8_t* out, Dims d, Box box) {
     const size_t n = box.d.nvox();
-    const size_t hw = (size_t)box.d.H * box.d.W;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (size_t)gridDim.x * blockDim.x) {
         int x, y, z;
         split3(c, box.d.H, box.d.W, x, y, z);
@@ -687,10 +684,9 @@ __global__ __launch_bounds__(TPB) void atom_first_kernel(const int* __restrict__
 
 __global__ __launch_bounds__(TPB) void atom_face_flags_kernel(const int* __restrict__ ids, Dims d, bool zlo_face, bool zhi_face, int* flags) {
     const size_t nvox = d.nvox();
-    const size_t HW = (size_t)d.H * d.W;
     for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x) {
         int x, y, z;
-            split3(v, d.H, d.W, x, y, z);
+        split3(v, d.H, d.W, x, y, z);
         if (x == 0 || y == 0 || x == d.W - 1 || y == d.H - 1 || (zlo_face && z == 0) || (zhi_face && z == d.N - 1)) {
             const int a = ids[v];
             if (a) flags[a] = 1;
