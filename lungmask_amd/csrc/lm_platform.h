@@ -177,8 +177,39 @@ __device__ __forceinline__ void lm_barrier_lds() { asm volatile("s_waitcnt lgkmc
 #if defined(LM_H3_TRACE) && defined(LM_EMU_BUILD)
 #undef LM_H3_TRACE  // the trace reads the shader clock: hardware only
 #endif
-#ifdef LM_H3_TRACE
+#if defined(LM_H3_TIMELINE) && !defined(LM_EMU_BUILD)
+// Timeline form (lab builds: -DLM_H3_TIMELINE): workgroups 0 and LM_TL_WG2 record (mark id, shader clock) per wave into 8 KiB
+// of LDS (256 events per wave) and copy them to lm_h3_trace_ptr ([2][8][256] unsigned: id << 28 | clock & 0xfffffff) at the end.
 extern __device__ unsigned* lm_h3_trace_ptr;
+#ifndef LM_TL_WG2
+#define LM_TL_WG2 133
+#endif
+#define LM_TRACE_INIT()                           \
+    constexpr unsigned TLN_ = (G16 || HEAD) ? 128 : 256; \
+    __shared__ unsigned tl_[8][TLN_];             \
+    unsigned tl_n_ = 0;                           \
+    const bool tl_on_ = blockIdx.x == 0 || blockIdx.x == LM_TL_WG2
+#define LM_TRACE_MARK(K)                                                                                   \
+    do {                                                                                                   \
+        if (tl_on_ && tl_n_ < TLN_) {                                                                       \
+            const unsigned n_ = (unsigned)__builtin_amdgcn_s_memtime();                                    \
+            if ((threadIdx.x & 63) == 0) tl_[threadIdx.x >> 6][tl_n_] = ((unsigned)(K) << 28) | (n_ & 0xfffffffu); \
+            ++tl_n_;                                                                                       \
+        }                                                                                                  \
+    } while (0)
+#define LM_TRACE_SUB(K) LM_TRACE_MARK(K)
+#define LM_TRACE_FLUSH()                                                                                   \
+    do {                                                                                                   \
+        if (lm_h3_trace_ptr && tl_on_ && (threadIdx.x & 63) == 0) {                                        \
+            unsigned* o_ = lm_h3_trace_ptr + ((size_t)(blockIdx.x == 0 ? 0 : 1) * 8 + (threadIdx.x >> 6)) * 256; \
+            for (unsigned k_ = 0; k_ < 256; ++k_) o_[k_] = k_ < tl_n_ && k_ < TLN_ ? tl_[threadIdx.x >> 6][k_] : 0xffffffffu; \
+        }                                                                                                  \
+    } while (0)
+#elif defined(LM_H3_TRACE)
+extern __device__ unsigned* lm_h3_trace_ptr;
+#define LM_TRACE_SUB(K) \
+    do {                \
+    } while (0)
 #define LM_TRACE_INIT()                                     \
     unsigned tr_last_ = (unsigned)__builtin_amdgcn_s_memtime(); \
     unsigned tr_sum_[6] = {0u, 0u, 0u, 0u, 0u, 0u}
@@ -204,6 +235,9 @@ extern __device__ unsigned* lm_h3_trace_ptr;
     } while (0)
 #define LM_TRACE_FLUSH() \
     do {                 \
+    } while (0)
+#define LM_TRACE_SUB(K) \
+    do {                \
     } while (0)
 #endif
 
@@ -296,6 +330,14 @@ __device__ __forceinline__ void lm_unsplit4(uint2 hi, uint2 lo, float* out) {
 #endif
 }
 
+// Pins the order of the statements around it (the compiler otherwise moves matrix instructions across the hand-issued reads)
+#ifdef LM_EMU_BUILD
+#define LM_SCHED_FENCE() \
+    do {                 \
+    } while (0)
+#else
+#define LM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 // 16-byte LDS reads that the compiler's waitcnt pass cannot see (so it does not drain an in-flight LDS-DMA
 // in front of them), with an explicit counted wait that names every destination register.
 #ifdef LM_EMU_BUILD

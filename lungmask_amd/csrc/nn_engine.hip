@@ -363,7 +363,6 @@ struct Fwd {
 
     bool head_fused = false;  // set by conv() when the head ran inside the last conv's epilogue
     int abl = 0;              // LM_LAB_HOOKS builds only: kernels left out by tools/bw_tail_ablation.py
-    int kcu = 0;              // profiler kind of conv1x1_up2x_h3
 
     int conv(const ConvLayer& L, const float* in, int in_cs, int in_co, int H, int W, float* out, int out_cs, int out_co,
              float* pool = nullptr, int pool_cs = 0, int pool_co = 0, const HeadParams* head = nullptr) {
@@ -440,53 +439,6 @@ struct Fwd {
         }
         return LM_OK;
     }
-
-    // up.1 of a decoder block (1x1 conv, commuted to LOW resolution) + the bilinear x2 in one kernel, straight into the first half
-    // of the level's concat buffer (split-f16 path).  Opt-in (LM_H3_FUSE_UP=1): bit-identical, but not faster than the two kernels
-    // (0.46 vs 0.42 ms per batch).  *done = false: the caller runs the two kernels.
-    int conv1x1_up2x(const ConvLayer& L, const float* in, int in_cs, int in_co, int h, int w, float* out, int out_cs, int out_co, bool* done) {
-        static const bool enabled = [] { const char* v = getenv("LM_H3_FUSE_UP"); return v && v[0] == '1'; }();
-        *done = false;
-        if (!h3 || !enabled || abl != 0 || L.taps != 1) return LM_OK;  // (env read once: A/B runs use one process per arm)
-        ConvParamsH3 q{};
-        q.in = reinterpret_cast<const char*>(in);
-        q.in_cstride = in_cs;
-        q.in_coff = in_co;
-        q.w = L.w_h3;
-        q.acc_scale = L.h3_acc_scale;
-        q.bias = defer ? L.bias_h3 : L.bias;
-        q.bn_s = L.bn_s;
-        q.border_corr = nullptr;  // 1x1: no halo, the producer's deferred shift is folded into the bias
-        q.out = reinterpret_cast<char*>(out);
-        q.out_cstride = out_cs;
-        q.out_coff = out_co;
-        q.range_flag = e->range_flag;
-        q.B = B;
-        q.H = h;
-        q.W = w;
-        q.Cin = L.cin;
-        q.Cout = L.cout;
-        if (!conv1x1_up2x_h3_ok(q)) return LM_OK;
-#ifdef LM_LAB_HOOKS
-        if (const char* v = getenv("LM_LAB_UPVAR")) q.head_C = atoi(v);
-#endif
-        const double px = (double)B * h * w;
-        int kind = kcu;
-        if (e->prof.on && e->prof.per_layer) {
-            char nm[48];
-            snprintf(nm, sizeof nm, "conv1x1_up2x_h3/H%d_Ci%d_Co%d", h, L.cin, L.cout);
-            kind = e->prof.kind_id(nm);
-        }
-        e->prof.begin(st, kind, 2.0 * px * L.cout * L.cin, 4.0 * (px * L.cin + 4.0 * px * L.cout + (double)L.cin * L.cout));
-        const hipError_t err = launch_conv1x1_up2x_h3(q, st);
-        e->prof.end(st);
-        if (err != hipSuccess) {
-            set_error("conv1x1 + upsample launch failed: %s (Cin=%d Cout=%d h=%d w=%d)", hipGetErrorString(err), L.cin, L.cout, h, w);
-            return LM_ERR_DEVICE;
-        }
-        *done = true;
-        return LM_OK;
-    }
 };
 
 }  // namespace
@@ -515,7 +467,6 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
     const bool h3 = e->precision == 1 && !md.force_f32;
     Fwd f{e, stream, B, e->prof.kind_id(h3 ? "conv3x3_igemm_h3" : "conv3x3_igemm_f32"), e->prof.kind_id(h3 ? "conv1x1_igemm_h3" : "conv1x1_igemm_f32"),
           e->prof.kind_id("first_conv"), e->prof.kind_id("upsample2x"), e->prof.kind_id("head_argmax"), h3};
-    f.kcu = e->prof.kind_id("conv1x1_up2x_h3");
     // LM_H3_DEFER_SHIFT=0: A/B hook (the tensors then hold the true activations, as in the exact-fp32 path)
     static const bool defer_ok = [] { const char* v = getenv("LM_H3_DEFER_SHIFT"); return !(v && v[0] == '0'); }();
     f.defer = h3 && defer_ok;
@@ -563,10 +514,8 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
     for (int i = 0; i < 4; ++i) {
         const int lvl = 3 - i;
         const int h = H >> lvl, w = W >> lvl, c = 64 << lvl;
-        bool fused_up = false;
-        LM_TRY(f.conv1x1_up2x(md.up1x1[i], t3, 2 * c, 0, h / 2, w / 2, ws.cat[lvl].as<float>(), 2 * c, 0, &fused_up));
-        if (!fused_up) LM_TRY(f.conv(md.up1x1[i], t3, 2 * c, 0, h / 2, w / 2, t2, c, 0));
-        if (!fused_up && !(abl & 4)) {
+        LM_TRY(f.conv(md.up1x1[i], t3, 2 * c, 0, h / 2, w / 2, t2, c, 0));
+        if (!(abl & 4)) {
             UpsampleParams p{t2, ws.cat[lvl].as<float>(), 2 * c, 0, B, h / 2, w / 2, c};
             const double opx = (double)B * h * w;
             e->prof.begin(stream, f.kup, 0, 4.0 * (opx * c + opx / 4 * c));

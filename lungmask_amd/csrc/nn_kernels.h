@@ -88,9 +88,6 @@ constexpr float kF16Guard = 32768.f;  // 2^15: a factor 2 below the largest fini
 bool conv3x3_h3_can_fuse_head(const ConvParamsH3& p);
 hipError_t launch_conv3x3_h3(const ConvParamsH3& p, hipStream_t stream);
 hipError_t launch_conv1x1_h3(const ConvParamsH3& p, hipStream_t stream);
-// 1x1 conv at low resolution + bilinear x2 in one kernel (p: the 1x1 conv on [B][H][W]; p.out: [B][2H][2W][out_cstride] at out_coff)
-bool conv1x1_up2x_h3_ok(const ConvParamsH3& p);
-hipError_t launch_conv1x1_up2x_h3(const ConvParamsH3& p, hipStream_t stream);
 hipError_t launch_first_conv_h3(const FirstConvParams& p, hipStream_t stream);  // out: split tensor
 hipError_t launch_upsample2x_h3(const UpsampleParams& p, hipStream_t stream);   // in/out: split tensors
 hipError_t launch_head_h3(const HeadParams& p, hipStream_t stream);             // in: split tensor

@@ -26,7 +26,7 @@
 
 #include "nn_kernels.h"
 
-#ifdef LM_H3_TRACE  // lab builds only (tools/ubench/conv_lab.hip)
+#if defined(LM_H3_TRACE) || defined(LM_H3_TIMELINE)  // lab builds only (tools/ubench/conv_lab.hip)
 __device__ unsigned* lm_h3_trace_ptr = nullptr;
 #endif
 
@@ -789,525 +789,6 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
     LM_TRACE_FLUSH();
 }
 
-// ---------------------------------------------------------------------------------------------
-// The 3x3 form on v_mfma_f32_16x16x32_f16 (opt-in: LM_H3_MMA=16; conv_igemm_h3p<9> is the default, see the launcher).
-//
-// Why a second instruction shape: the chip clocks to its power budget, and per FLOP the 16x16x32 instruction moves half the
-// accumulator traffic of 32x32x16 -- on this network's operands the bare instruction stream sustains 1995 instead of 1737
-// TFLOP/s (tools/ubench/mfma_power.hip).  Same workgroup tile, LDS image, DMA, barrier protocol and item pipeline as
-// conv_igemm_h3p; what changes is how a chunk (16 input channels x 9 taps) is fed to the matrix pipes.  K = 32 per
-// instruction = TWO 16-deep operands side by side (lane quarters q = lane >> 4 are the four 8-deep k-blocks):
-//   M1(tap)      w_hi | w_hi   x   a_hi | a_lo      ->  w_hi*a_hi + w_hi*a_lo of one tap          (9 per chunk)
-//   M2(tap pair) w_lo(t) | w_lo(t+1)  x  a_hi(t) | a_hi(t+1)  ->  w_lo*a_hi of two taps            (4 per chunk)
-//   M2(8, none)  w_lo(8) | 0   x   a_hi(8) | (any)  ->  the odd ninth tap; its upper half multiplies zeros  (1 per chunk)
-// 14 phases of 8 fragment reads + 16 matrix instructions (4 M-tiles of 16 couts x 4 N-tiles of 16 pixels per wave; the
-// accumulator is 64 registers as before), against 13.5 phases of arithmetic: 3.7 % of the instructions multiply by zero.
-// The phases are a two-set register pipeline (reads of phase k+1 under the MFMAs of phase k) that runs through the chunk
-// barrier exactly like the tap pipeline of conv_igemm_h3p (14 is even: the sets keep their roles from chunk to chunk).
-// The swizzle of the LDS image is a function of the halo column / weight row (16-byte slot ^= gray((index >> 1) & 3)), so that
-// every fragment read of every phase is bank-conflict free for both geometries (enumerated: tools/README).
-namespace {
-__device__ __forceinline__ int lm_gray2(int j) { return j ^ (j >> 1); }
-}  // namespace
-
-#define H3Q_NTOFF(NT) (G16 ? (NT) * ROWB : ((NT) >> 1) * ROWB + ((NT) & 1) * 1024)
-// M1 of tap (DY, DX): F[0..3] = w_hi|w_hi of the four M-tiles, F[4..7] = a_hi|a_lo of the four N-tiles
-#define H3Q_READS_M1(F, AS, DY, DX)                                                                 \
-    if (!abl_r) {                                                                                   \
-        LM_LDS_READ128(F[0], (AS) + a1_off, (3 * (DY) + (DX)) * 4096);                              \
-        LM_LDS_READ128(F[1], (AS) + a1_off, (3 * (DY) + (DX)) * 4096 + 1024);                       \
-        LM_LDS_READ128(F[2], (AS) + a1_off, (3 * (DY) + (DX)) * 4096 + 2048);                       \
-        LM_LDS_READ128(F[3], (AS) + a1_off, (3 * (DY) + (DX)) * 4096 + 3072);                       \
-        LM_LDS_READ128(F[4], (AS) + b1_off[DX], (DY) * ROWB + H3Q_NTOFF(0));                        \
-        LM_LDS_READ128(F[5], (AS) + b1_off[DX], (DY) * ROWB + H3Q_NTOFF(1));                        \
-        LM_LDS_READ128(F[6], (AS) + b1_off[DX], (DY) * ROWB + H3Q_NTOFF(2));                        \
-        LM_LDS_READ128(F[7], (AS) + b1_off[DX], (DY) * ROWB + H3Q_NTOFF(3));                        \
-    } else                                                                                          \
-        (void)0
-// M2 of the tap pair starting at tap T0 (its first tap is (DYB, .)); BT picks the per-lane activation offset of the pair's
-// column/row pattern (b2_off)
-#define H3Q_READS_M2(F, AS, T0, BT, DYB)                                                            \
-    if (!abl_r) {                                                                                   \
-        LM_LDS_READ128(F[0], (AS) + a2_off, (T0) * 4096);                                           \
-        LM_LDS_READ128(F[1], (AS) + a2_off, (T0) * 4096 + 1024);                                    \
-        LM_LDS_READ128(F[2], (AS) + a2_off, (T0) * 4096 + 2048);                                    \
-        LM_LDS_READ128(F[3], (AS) + a2_off, (T0) * 4096 + 3072);                                    \
-        LM_LDS_READ128(F[4], (AS) + b2_off[BT], (DYB) * ROWB + H3Q_NTOFF(0));                       \
-        LM_LDS_READ128(F[5], (AS) + b2_off[BT], (DYB) * ROWB + H3Q_NTOFF(1));                       \
-        LM_LDS_READ128(F[6], (AS) + b2_off[BT], (DYB) * ROWB + H3Q_NTOFF(2));                       \
-        LM_LDS_READ128(F[7], (AS) + b2_off[BT], (DYB) * ROWB + H3Q_NTOFF(3));                       \
-    } else                                                                                          \
-        (void)0
-// the ninth tap alone: the upper k-blocks of the weight operand come from the zero slab (A2Z = this buffer's per-lane pointer)
-#define H3Q_READS_M2Z(F, AS, A2Z)                                                                   \
-    if (!abl_r) {                                                                                   \
-        LM_LDS_READ128(F[0], (A2Z), 8 * 4096);                                                      \
-        LM_LDS_READ128(F[1], (A2Z), 8 * 4096 + 1024);                                               \
-        LM_LDS_READ128(F[2], (A2Z), 8 * 4096 + 2048);                                               \
-        LM_LDS_READ128(F[3], (A2Z), 8 * 4096 + 3072);                                               \
-        LM_LDS_READ128(F[4], (AS) + b2_off[3], 2 * ROWB + H3Q_NTOFF(0));                            \
-        LM_LDS_READ128(F[5], (AS) + b2_off[3], 2 * ROWB + H3Q_NTOFF(1));                            \
-        LM_LDS_READ128(F[6], (AS) + b2_off[3], 2 * ROWB + H3Q_NTOFF(2));                            \
-        LM_LDS_READ128(F[7], (AS) + b2_off[3], 2 * ROWB + H3Q_NTOFF(3));                            \
-    } else                                                                                          \
-        (void)0
-#define H3Q_MFMA4(F, MT)                                                                    \
-    do {                                                                                    \
-        accq[MT][0] = lm_mfma_f32_16x16x32_f16(F[MT], F[4], accq[MT][0]);                   \
-        accq[MT][1] = lm_mfma_f32_16x16x32_f16(F[MT], F[5], accq[MT][1]);                   \
-        accq[MT][2] = lm_mfma_f32_16x16x32_f16(F[MT], F[6], accq[MT][2]);                   \
-        accq[MT][3] = lm_mfma_f32_16x16x32_f16(F[MT], F[7], accq[MT][3]);                   \
-    } while (0)
-#define H3Q_MFMAS(F)     \
-    do {                 \
-        H3Q_MFMA4(F, 0); \
-        H3Q_MFMA4(F, 1); \
-        H3Q_MFMA4(F, 2); \
-        H3Q_MFMA4(F, 3); \
-    } while (0)
-#define H3Q_MFMAS_D(F, K0)   \
-    do {                     \
-        H3Q_MFMA4(F, 0);     \
-        dma_slot((K0) + 0);  \
-        H3Q_MFMA4(F, 1);     \
-        dma_slot((K0) + 1);  \
-        H3Q_MFMA4(F, 2);     \
-        dma_slot((K0) + 2);  \
-        H3Q_MFMA4(F, 3);     \
-        dma_slot((K0) + 3);  \
-    } while (0)
-// one phase: READS is the (already parenthesised) read macro call of the NEXT phase into FN
-#define H3Q_PHASE(FC, READS_NEXT) \
-    do {                          \
-        READS_NEXT;               \
-        H3P_WAITF(8, FC);         \
-        H3Q_MFMAS(FC);            \
-    } while (0)
-#define H3Q_PHASE_D(FC, READS_NEXT, K0) \
-    do {                                \
-        READS_NEXT;                     \
-        H3P_WAITF(8, FC);               \
-        H3Q_MFMAS_D(FC, K0);            \
-    } while (0)
-// phases 0..12 of the chunk in buffer AS (phase 0 already in flight in f); leaves phase 13 (the zero-padded ninth tap) in
-// flight in g.  Phase order: M1(0,0) M1(0,1) M2(0|1) M1(0,2) M1(1,0) M2(2|3) M1(1,1) M1(1,2) M2(4|5) M1(2,0) M1(2,1) M2(6|7)
-// M1(2,2) M2(8|-)
-#define H3Q_CHUNK_PHASES(AS, A2Z)                                  \
-    do {                                                           \
-        H3Q_PHASE_D(f, H3Q_READS_M1(g, AS, 0, 1), 0);              \
-        H3Q_PHASE_D(g, H3Q_READS_M2(f, AS, 0, 0, 0), 4);           \
-        H3Q_PHASE_D(f, H3Q_READS_M1(g, AS, 0, 2), 8);              \
-        H3Q_PHASE(g, H3Q_READS_M1(f, AS, 1, 0));                   \
-        H3Q_PHASE(f, H3Q_READS_M2(g, AS, 2, 1, 0));                \
-        H3Q_PHASE(g, H3Q_READS_M1(f, AS, 1, 1));                   \
-        H3Q_PHASE(f, H3Q_READS_M1(g, AS, 1, 2));                   \
-        H3Q_PHASE(g, H3Q_READS_M2(f, AS, 4, 2, 1));                \
-        H3Q_PHASE(f, H3Q_READS_M1(g, AS, 2, 0));                   \
-        H3Q_PHASE(g, H3Q_READS_M1(f, AS, 2, 1));                   \
-        H3Q_PHASE(f, H3Q_READS_M2(g, AS, 6, 0, 2));                \
-        H3Q_PHASE(g, H3Q_READS_M1(f, AS, 2, 2));                   \
-        H3Q_PHASE(f, H3Q_READS_M2Z(g, AS, A2Z));                   \
-    } while (0)
-
-template <bool G16, bool HEAD = false>
-__global__ __launch_bounds__(512) void conv_igemm_h3q(ConvParamsH3 p, int n_ptiles, int n_items, int xcd_order) {
-    constexpr int TAPS = 9;
-    using SM = H3WSmem<TAPS, G16>;
-    constexpr int HALO = SM::HALO, PW = SM::PW, TWW = SM::TWW, NW = SM::NW, ROWB = PW * 64;
-    constexpr int PSTR = 272;  // staged pixel stride of the epilogue: 256 B of split data + 16 B pad
-    static_assert(NW * 32 * PSTR <= SM::BUF_BYTES, "the epilogue stages through the buffer of the last chunk");
-    constexpr int ZSLAB = 2 * SM::BUF_BYTES;  // 4 KiB of zeros behind the two chunk buffers (the "tenth tap" of M2(8|-))
-    __shared__ __attribute__((aligned(1024))) char lds[2 * SM::BUF_BYTES + 4096];
-    __shared__ __attribute__((aligned(16))) float epi[2][3][TN];  // bias, bn scale, bn shift of the item (double buffered)
-    __shared__ __attribute__((aligned(16))) float hw[HEAD ? kMaxClasses * 64 + kMaxClasses : 4];  // fused head: weights, bias
-    static_assert(!HEAD || !G16, "the fused head belongs to the 32-wide form");
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = lm_uniform(tid >> 6);
-    const int i16 = lane & 15, q = lane >> 4;  // element of the 16-wide MFMA tile, k-block / accumulator row quad
-    // wave -> pixels.  G32: rows 2w, 2w+1 of the tile; N-tile nt = 2 * row + column half.  G16: slice w >> 2, rows
-    // 4 (w & 3) .. +3; N-tile nt = row.
-    const int wsl = G16 ? (wave >> 2) : 0;
-    const int wrow0 = G16 ? 4 * (wave & 3) : 2 * wave;
-
-    // ---- fragment byte offsets inside a buffer (item invariant).  Logical 16-byte slots of a 64-byte row: 0 = hi of channels
-    // 0..7, 1 = their lo, 2 = hi of channels 8..15, 3 = their lo; physical slot = logical ^ gray((column or row >> 1) & 3).
-    auto act_off = [&](int drow, int dcol, int slot) -> int {
-        const int px = i16 + dcol;
-        return (wsl * SM::SL_ROWS + (wrow0 + drow) * PW + px) * 64 + ((slot ^ lm_gray2((px >> 1) & 3)) * 16);
-    };
-    const int wsw = lm_gray2((i16 >> 1) & 3);
-    int b1_off[3], b2_off[4];
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) b1_off[dx] = act_off(0, dx, ((q & 1) << 1) | (q >> 1));  // a_hi g0, a_hi g1, a_lo g0, a_lo g1
-    b2_off[0] = act_off(0, (q >> 1) ? 1 : 0, (q & 1) << 1);          // taps (dy,0) | (dy,1)
-    b2_off[1] = act_off((q >> 1) ? 1 : 0, (q >> 1) ? 0 : 2, (q & 1) << 1);  // taps (0,2) | (1,0)
-    b2_off[2] = act_off(0, (q >> 1) ? 2 : 1, (q & 1) << 1);          // taps (1,1) | (1,2)
-    b2_off[3] = act_off(0, 2, (q & 1) << 1);                          // tap (2,2) | anything valid
-    const int a1_off = SM::A_BYTES + i16 * 64 + ((((q & 1) << 1) ^ wsw) * 16);                          // w_hi g0, g1, g0, g1
-    const int a2_off = SM::A_BYTES + ((q >> 1) * 64 + i16) * 64 + (((1 + ((q & 1) << 1)) ^ wsw) * 16);  // w_lo of tap t | t+1
-    // M2(8|-): lower k-blocks as a2_off, upper k-blocks from the zero slab (the immediate 8 * 4096 + mt * 1024 is added to both)
-    const char* a2z[2];
-#pragma unroll
-    for (int bsel = 0; bsel < 2; ++bsel)
-        a2z[bsel] = (q >> 1) ? lds + ZSLAB - 8 * 4096 + i16 * 64 + (((1 + ((q & 1) << 1)) ^ wsw) * 16) : lds + bsel * SM::BUF_BYTES + a2_off;
-
-    // ---- DMA lane geometry (item invariant): which halo pixel / weight row this lane feeds
-    unsigned relA[SM::A_PER_WAVE];  // source offset of this lane's 16 bytes relative to the halo tile's top-left pixel
-    int pyx[SM::A_PER_WAVE];        // py | px << 8 | slice << 16, or -1 when the lane has nothing to do for that piece
-#pragma unroll
-    for (int j = 0; j < SM::A_PER_WAVE; ++j) {
-        const int piece = wave + NW * j, idx = piece * 64 + lane;
-        pyx[j] = -1;
-        relA[j] = 0;
-        if (piece < SM::A_PIECES && idx < SM::A_ROWS * 4) {
-            const int row = idx >> 2;
-            const int sl = row / SM::SL_ROWS, rr = row - sl * SM::SL_ROWS;
-            const int py = rr / PW, px = rr - py * PW;
-            const int ls = (idx & 3) ^ lm_gray2((px >> 1) & 3);  // logical 16-byte slot behind this lane's physical one
-            relA[j] = (unsigned)(((sl * p.H + py) * p.W + px) * p.in_cstride * 4 + (ls >> 1) * 32 + (ls & 1) * 16);
-            pyx[j] = py | (px << 8) | (sl << 16);
-        }
-    }
-    unsigned voffW;  // weight row of this lane in piece `wave`; piece wave + 8 j lies two taps further per j
-    {
-        const int idx = wave * 64 + lane;
-        const int row = idx >> 2, ls = (idx & 3) ^ lm_gray2((row >> 1) & 3);
-        const int tap = row / TN, n = row - tap * TN;
-        voffW = (unsigned)((tap * p.Cout + n) * p.Cin * 4 + (ls >> 1) * 32 + (ls & 1) * 16);
-    }
-    const unsigned w_piece_stride = (unsigned)(NW * 64 / 4 / TN) * (unsigned)p.Cout * (unsigned)p.Cin * 4u;
-    const unsigned slice_bytes = (unsigned)p.H * (unsigned)p.W * (unsigned)p.in_cstride * 4u;
-    const lm_rsrc rsrcA = lm_make_rsrc(p.in + (size_t)p.in_coff * 4, (size_t)p.B * slice_bytes - (size_t)p.in_coff * 4);
-    const lm_rsrc rsrcW = lm_make_rsrc(p.w, (size_t)TAPS * p.Cout * p.Cin * 4);
-    const int tiles_x = p.W / TWW;
-    const int nchunks = p.Cin / KC;  // even (checked by the launcher)
-    const bool bn = p.bn_s != nullptr;
-
-    // Work-item order: see conv_igemm_h3p
-    const int n_ct = p.Cout / TN;
-    const int tiles_y = (p.H + TH - 1) / TH;
-    const bool pow2 = ((n_ct & (n_ct - 1)) | (tiles_x & (tiles_x - 1)) | (tiles_y & (tiles_y - 1))) == 0;
-    const int sh_ct = 31 - __clz(n_ct), sh_tx = 31 - __clz(tiles_x), sh_ty = 31 - __clz(tiles_y);
-    auto decode = [&](int it, int& b, int& y0, int& x0, int& n0) -> bool {
-        int ct, pt;
-        if (xcd_order) {
-            const int x = it & 7, s = it >> 3;
-            ct = pow2 ? (s & (n_ct - 1)) : s % n_ct;
-            pt = (pow2 ? (s >> sh_ct) : s / n_ct) * 8 + x;
-        } else {
-            ct = it / n_ptiles;
-            pt = it - ct * n_ptiles;
-        }
-        const bool valid = pt < n_ptiles;
-        const int tx = pow2 ? (pt & (tiles_x - 1)) : pt % tiles_x;
-        pt = pow2 ? (pt >> sh_tx) : pt / tiles_x;
-        const int ty = pow2 ? (pt & (tiles_y - 1)) : pt % tiles_y;
-        b = (pow2 ? (pt >> sh_ty) : pt / tiles_y) * SM::NSL;  // first slice of the item
-        y0 = ty * TH;
-        x0 = tx * TWW;
-        n0 = ct * TN;
-        return valid;
-    };
-    auto item_voffs = [&](int b, int y0, int x0, unsigned* voff) __attribute__((always_inline)) {
-        const int ioff = ((y0 - HALO) * p.W + (x0 - HALO)) * p.in_cstride * 4;  // may be negative; the sum below is not
-#pragma unroll
-        for (int j = 0; j < SM::A_PER_WAVE; ++j) {
-            const int gy = y0 + (pyx[j] & 0xff) - HALO, gx = x0 + ((pyx[j] >> 8) & 0xff) - HALO;
-            const bool inb = pyx[j] >= 0 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && b + (pyx[j] >> 16) < p.B;
-            voff[j] = inb ? (unsigned)((int)relA[j] + ioff) : LM_DMA_OOB;
-        }
-    };
-
-    unsigned voffC[SM::A_PER_WAVE], voffN[SM::A_PER_WAVE];  // this item's / the next item's source offsets
-    // ---- the pending stage: the chunk whose DMA pieces the slots of the running phases issue (see conv_igemm_h3p)
-    bool d_next = false;
-    unsigned d_soffA = 0, d_soffW = 0;
-    char* d_buf = lds;
-    int d_nA = 0, d_nW = 0, d_epi = -1, d_n0 = 0;
-    auto set_dma = [&](bool next_item, int b, int n0, int c0, int par, bool on, int epar_or_neg) __attribute__((always_inline)) {
-        d_next = next_item;
-        d_soffA = (unsigned)b * slice_bytes + (unsigned)c0 * 4u;
-        d_soffW = ((unsigned)n0 * (unsigned)p.Cin + (unsigned)c0) * 4u;
-        d_buf = lds + par * SM::BUF_BYTES;
-        on = on && !LM_ABL_DMA(c0);
-        d_nA = on ? SM::A_PIECES : 0;
-        d_nW = on ? SM::W_PIECES : 0;
-        d_epi = on ? epar_or_neg : -1;
-        d_n0 = n0;
-    };
-    constexpr int N_SLOTS = 12;
-    static_assert(2 * SM::A_PER_WAVE <= N_SLOTS && 2 * SM::W_PER_WAVE + 1 <= N_SLOTS, "DMA slots");
-    const float* const epi_src = (wave == 0 ? p.bias : (wave == 1 ? p.bn_s : p.bn_t)) + lane;
-    auto dma_slot = [&](int k) __attribute__((always_inline)) {
-        const int j = k >> 1;
-        if (k == N_SLOTS - 1) {
-            if (d_epi >= 0 && wave < (bn ? 3 : 1)) lm_dma4_global(epi_src + d_n0, &epi[d_epi][wave][0]);
-        } else if ((k & 1) == 0) {
-            if (j < SM::A_PER_WAVE && wave + NW * j < d_nA) {
-                const int jj = j < SM::A_PER_WAVE ? j : 0;
-                const unsigned vc = voffC[jj], vn = voffN[jj];  // (both read as VALUES: a select between the arrays themselves sends them to scratch)
-                lm_dma16(rsrcA, d_next ? vn : vc, d_soffA, d_buf + (wave + NW * j) * 1024);
-            }
-        } else {
-            if (j < SM::W_PER_WAVE && wave + NW * j < d_nW)
-                lm_dma16(rsrcW, voffW, d_soffW + (unsigned)j * w_piece_stride, d_buf + SM::A_BYTES + (wave + NW * j) * 1024);
-        }
-    };
-
-    lm_f32x4 accq[4][4];  // [M-tile of 16 couts][N-tile of 16 pixels]: lane (i16, q) holds couts 16 mt + 4 q + r of pixel i16
-    int it = blockIdx.x;
-    int b, y0, x0, n0;
-    while (it < n_items && !decode(it, b, y0, x0, n0)) it += gridDim.x;
-    if (it >= n_items) return;
-    if (!bn && tid < 2 * TN) {  // no BatchNorm: identity constants, never overwritten
-        epi[0][1 + tid / TN][tid % TN] = tid < TN ? 1.f : 0.f;
-        epi[1][1 + tid / TN][tid % TN] = tid < TN ? 1.f : 0.f;
-    }
-    if (tid < 256) {  // the zero slab
-        const uint4 z = {0u, 0u, 0u, 0u};
-        *reinterpret_cast<uint4*>(lds + ZSLAB + tid * 16) = z;
-    }
-    if constexpr (HEAD) {
-        for (int i = tid; i < p.head_C * 64; i += 512) hw[i] = p.head_w[i];
-        if (tid < p.head_C) hw[kMaxClasses * 64 + tid] = p.head_b[tid];
-    }
-    item_voffs(b, y0, x0, voffC);
-    int epar = 0;
-    char* const buf0 = lds;
-    char* const buf1 = lds + SM::BUF_BYTES;
-    // prologue: chunk 0 of the first item, all pieces at once
-    set_dma(false, b, n0, 0, 0, true, epar);
-#pragma unroll
-    for (int k = 0; k < N_SLOTS; ++k) dma_slot(k);
-    lm_barrier_dma();
-    LM_TRACE_INIT();
-    while (true) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    accq[i][j][r] = 0.f;
-                }
-        int nit = it + gridDim.x;
-        int nb = 0, ny0 = 0, nx0 = 0, nn0 = 0;
-        while (nit < n_items && !decode(nit, nb, ny0, nx0, nn0)) nit += gridDim.x;
-        const bool have_next = nit < n_items;
-        item_voffs(nb, ny0, nx0, voffN);
-        lm_h16x8 f[8], g[8];  // two fragment sets: 4 weight operands (M-tiles), 4 activation operands (N-tiles)
-        bool abl_r = false;   // lab ablation (constant false in the product)
-        set_dma(false, b, n0, KC, 1, true, -1);  // chunk 1 -> buffer 1, issued from the slots of chunk 0
-        H3Q_READS_M1(f, buf0, 0, 0);
-        for (int ci = 0; ci < nchunks; ci += 2) {
-            abl_r = LM_ABL_READS(ci);
-            // ---- even chunk ci (buffer 0)
-            H3Q_CHUNK_PHASES(buf0, a2z[0]);
-            H3P_WAITF(0, g);
-            LM_TRACE_MARK(0);
-            lm_barrier_dma();  // everyone has read buffer 0 for the last time; chunk ci + 1 is complete in buffer 1
-            LM_TRACE_MARK(1);
-            H3Q_READS_M1(f, buf1, 0, 0);
-            if (ci + 2 < nchunks) set_dma(false, b, n0, (ci + 2) * KC, 0, true, -1);
-            else set_dma(true, nb, nn0, 0, 0, have_next, epar ^ 1);  // the next item's chunk 0 + epilogue constants
-            H3Q_MFMAS(g);
-            // ---- odd chunk ci + 1 (buffer 1)
-            H3Q_CHUNK_PHASES(buf1, a2z[1]);
-            H3P_WAITF(0, g);
-            LM_TRACE_MARK(0);
-            lm_barrier_dma();
-            LM_TRACE_MARK(1);
-            if (ci + 2 < nchunks) {
-                H3Q_READS_M1(f, buf0, 0, 0);
-                set_dma(false, b, n0, (ci + 3) * KC, 1, true, -1);
-            } else {
-                set_dma(false, b, n0, 0, 1, false, -1);  // buffer 1 becomes the epilogue's staging area
-            }
-            H3Q_MFMAS(g);
-        }
-        LM_TRACE_MARK(2);
-        // ---- epilogue of this item (the first chunk of the next item is already resident in buffer 0).  Accumulator layout:
-        // lane (i16, q), N-tile nt: one pixel; M-tile mt: its output channels 16 mt + 4 q .. + 3.  A "row pass" R covers the
-        // N-tiles 2R, 2R + 1 = 32 pixels: one image row of the 32-wide tile, two image rows of the 16-wide one.
-        {
-            char* stage = buf1 + wave * (32 * PSTR);
-            const int bs = b + wsl;
-            const int yb = y0 + wrow0;  // image row of the wave's N-tile 0
-            const int Hp = p.H >> 1, Wp = p.W >> 1;
-            const char* ep = reinterpret_cast<const char*>(&epi[epar][0][0]);
-            unsigned gmax = 0u;  // running max of the |hi| halves this lane writes (f16 range guard)
-            // the item's epilogue constants of this lane's 16 channels: loaded once (the fragment registers are free now)
-            float cb[4][4], cs[4][4], ct[4][4];
-            {
-                lm_h16x8 e[4][3];
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    LM_LDS_READ128(e[mt][0], ep + (16 * mt + 4 * q) * 4, 0);
-                    LM_LDS_READ128(e[mt][1], ep + (16 * mt + 4 * q) * 4, TN * 4);
-                    LM_LDS_READ128(e[mt][2], ep + (16 * mt + 4 * q) * 4, 2 * TN * 4);
-                }
-                LM_LDS_WAIT6(0, e[0][0], e[0][1], e[0][2], e[1][0], e[1][1], e[1][2]);
-                LM_LDS_WAIT6(0, e[2][0], e[2][1], e[2][2], e[3][0], e[3][1], e[3][2]);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    const float4 a = as_float4(e[mt][0]), s4 = as_float4(e[mt][1]), t4 = as_float4(e[mt][2]);
-                    cb[mt][0] = a.x; cb[mt][1] = a.y; cb[mt][2] = a.z; cb[mt][3] = a.w;
-                    cs[mt][0] = s4.x; cs[mt][1] = s4.y; cs[mt][2] = s4.z; cs[mt][3] = s4.w;
-                    ct[mt][0] = t4.x; ct[mt][1] = t4.y; ct[mt][2] = t4.z; ct[mt][3] = t4.w;
-                }
-            }
-            if constexpr (HEAD) {
-                // ---- fused head (n0 == 0: the item holds all 64 channels of its pixels, 16 per lane of a quad q = 0..3).
-                // launch_head_h3 sums each 8-channel block as one fma chain (k = 0..7 from 0) and adds the blocks pairwise
-                // (b ^ 4, b ^ 2, b ^ 1).  Block 2 mt + (q >> 1) lives in the lane pair (q, q ^ 1): the even lane runs k = 0..3,
-                // hands the partial sum over (lane ^ 16) and the odd lane finishes k = 4..7; the odd lanes then hold blocks
-                // {0,2,4,6} (q = 1) and {1,3,5,7} (q = 3) and the tree closes with one exchange (lane ^ 32) -- on the values a
-                // reader of the split tensor would see, so the labels are bit-identical to the unfused path.
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const int yl = yb + (nt >> 1), xl = x0 + 16 * (nt & 1) + i16;
-                    const bool tile_ok = bs < p.B && yl < p.H;
-                    const int bmask = (yl == 0 ? 1 : 0) | (yl == p.H - 1 ? 2 : 0) | (xl == 0 ? 4 : 0) | (xl == p.W - 1 ? 8 : 0);
-                    const bool border = p.border_corr != nullptr && __any(bmask != 0);  // wave-uniform
-                    float vv[4][4];
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) {
-                        float bb[4] = {cb[mt][0], cb[mt][1], cb[mt][2], cb[mt][3]};
-                        if (border) {
-                            const float4 c = *reinterpret_cast<const float4*>(p.border_corr + (size_t)bmask * p.Cout + n0 + 16 * mt + 4 * q);
-                            bb[0] -= c.x; bb[1] -= c.y; bb[2] -= c.z; bb[3] -= c.w;
-                        }
-                        float v[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            float t = fmaf(accq[mt][nt][k], p.acc_scale, bb[k]);
-                            if (bn) t = fmaf(fmaxf(t, 0.f), cs[mt][k], ct[mt][k]);
-                            v[k] = t;
-                        }
-                        uint2 ph, plo;
-                        lm_split4(v[0], v[1], v[2], v[3], &ph, &plo);
-                        gmax = lm_pk_absmax_u16(lm_pk_absmax_u16(gmax, ph.x), ph.y);
-                        lm_unsplit4(ph, plo, vv[mt]);
-                    }
-                    float best = 0.f;
-                    int arg = 0;
-                    for (int c = 0; c < p.head_C; ++c) {
-                        float sb[4];  // block 2 mt + (q >> 1), valid in the odd lanes of the quad
-#pragma unroll
-                        for (int mt = 0; mt < 4; ++mt) {
-                            const float4 w4 = *reinterpret_cast<const float4*>(&hw[c * 64 + 16 * mt + 4 * q]);
-                            float s0 = fmaf(vv[mt][0], w4.x, 0.f);  // chain from 0: right for the even lanes ...
-                            s0 = fmaf(vv[mt][1], w4.y, s0);
-                            s0 = fmaf(vv[mt][2], w4.z, s0);
-                            s0 = fmaf(vv[mt][3], w4.w, s0);
-                            float s1 = __shfl_xor(s0, 16);          // ... continued by the odd lane from its partner's partial sum
-                            s1 = fmaf(vv[mt][0], w4.x, s1);
-                            s1 = fmaf(vv[mt][1], w4.y, s1);
-                            s1 = fmaf(vv[mt][2], w4.z, s1);
-                            s1 = fmaf(vv[mt][3], w4.w, s1);
-                            sb[mt] = s1;
-                        }
-                        // q = 1: blocks 0, 2, 4, 6 -> (b0 + b4) + (b2 + b6); q = 3: blocks 1, 3, 5, 7 -> (b1 + b5) + (b3 + b7)
-                        const float half = (sb[0] + sb[2]) + (sb[1] + sb[3]);
-                        const float other = __shfl_xor(half, 32);
-                        const float lg = (q == 1 ? half + other : other + half) + hw[kMaxClasses * 64 + c];
-                        if (c == 0 || lg > best) {
-                            best = lg;
-                            arg = c;
-                        }
-                    }
-                    if (tile_ok && q == 1) p.head_labels[((size_t)bs * p.H + yl) * p.W + xl] = (uint8_t)arg;
-                }
-            } else {
-                float pl[2][4][4];  // 2x2 average pool: sums over the two rows of a pool cell, per N-tile column half / row pair
-#pragma unroll
-                for (int R = 0; R < 2; ++R) {
-#pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        const int nt = 2 * R + hh;
-                        const int yl = G16 ? yb + nt : yb + R, xl = G16 ? i16 : x0 + 16 * hh + i16;
-                        const int bmask = (yl == 0 ? 1 : 0) | (yl == p.H - 1 ? 2 : 0) | (xl == 0 ? 4 : 0) | (xl == p.W - 1 ? 8 : 0);
-                        const bool border = p.border_corr != nullptr && __any(bmask != 0);  // wave-uniform
-#pragma unroll
-                        for (int mt = 0; mt < 4; ++mt) {
-                            const int cl = 16 * mt + 4 * q;  // first of 4 consecutive local output channels
-                            float bb[4] = {cb[mt][0], cb[mt][1], cb[mt][2], cb[mt][3]};
-                            if (border) {
-                                const float4 c = *reinterpret_cast<const float4*>(p.border_corr + (size_t)bmask * p.Cout + n0 + cl);
-                                bb[0] -= c.x; bb[1] -= c.y; bb[2] -= c.z; bb[3] -= c.w;
-                            }
-                            float v[4];
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                float t = fmaf(accq[mt][nt][k], p.acc_scale, bb[k]);
-                                if (bn) t = fmaf(fmaxf(t, 0.f), cs[mt][k], ct[mt][k]);
-                                v[k] = t;
-                                // pool partners in y: G32 rows yb, yb + 1 = passes R = 0, 1 of the same hh; G16 rows 2R, 2R + 1 = hh = 0, 1
-                                const int pi = G16 ? R : hh;
-                                const bool first = G16 ? hh == 0 : R == 0;
-                                pl[pi][mt][k] = first ? t : pl[pi][mt][k] + t;
-                            }
-                            uint2 ph, plo;
-                            lm_split4(v[0], v[1], v[2], v[3], &ph, &plo);
-                            gmax = lm_pk_absmax_u16(lm_pk_absmax_u16(gmax, ph.x), ph.y);
-                            char* d = stage + (16 * hh + i16) * PSTR + (cl >> 3) * 32 + (cl & 7) * 2;
-                            *reinterpret_cast<uint2_a*>(d) = ph;
-                            *reinterpret_cast<uint2_a*>(d + 16) = plo;
-                        }
-                    }
-                    // the wave's 32 pixels x 256 B of this pass are in LDS (same-wave LDS ops are ordered): stream them out.
-                    // G32: 32 consecutive pixels of image row yb + R; G16 (W == 16): rows yb + 2R, yb + 2R + 1 = 32 consecutive pixels.
-                    lm_wave_lds_fence();
-                    const int y_first = G16 ? yb + 2 * R : yb + R;
-                    const bool tile_ok = bs < p.B && (G16 ? y_first + 1 < p.H : y_first < p.H);
-                    if (tile_ok) {
-                        char* orow = p.out + ((((size_t)bs * p.H + y_first) * p.W + x0) * p.out_cstride + p.out_coff + n0) * 4;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const int qq = i * 64 + lane, px = qq >> 4, part = qq & 15;
-                            const uint4 val = *reinterpret_cast<const uint4_a*>(stage + px * PSTR + part * 16);
-                            *reinterpret_cast<uint4_a*>(orow + (size_t)px * p.out_cstride * 4 + part * 16) = val;
-                        }
-                    }
-                    lm_wave_lds_fence();  // the staging rows are rewritten by the next pass
-                }
-                if (p.pool != nullptr) {  // avg_pool2d(2): the y partner was summed above; x + 1 is lane ^ 1
-#pragma unroll
-                    for (int pi = 0; pi < 2; ++pi) {
-                        // G32: pi = column half, pooled row (yb >> 1), pooled column (x0 + 16 pi + i16) >> 1
-                        // G16: pi = row pair R, pooled row (yb + 2 pi) >> 1, pooled column i16 >> 1
-                        const int py_ = G16 ? (yb + 2 * pi) >> 1 : yb >> 1, px_ = G16 ? i16 >> 1 : (x0 + 16 * pi + i16) >> 1;
-                        char* prow = p.pool + ((((size_t)bs * Hp + py_) * Wp + px_) * p.pool_cstride + p.pool_coff) * 4;
-                        const bool ok = bs < p.B && (G16 ? yb + 2 * pi + 1 < p.H : yb + 1 < p.H);
-#pragma unroll
-                        for (int mt = 0; mt < 4; ++mt) {
-                            const int cg = n0 + 16 * mt + 4 * q;
-                            float qv[4];
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) qv[k] = 0.25f * (pl[pi][mt][k] + __shfl_xor(pl[pi][mt][k], 1));
-                            if (ok && (i16 & 1) == 0) split_store4(prow + (size_t)(cg >> 3) * 32, (cg & 7) * 2, qv[0], qv[1], qv[2], qv[3]);
-                        }
-                    }
-                }
-            }
-            if (p.range_flag != nullptr && lm_pk_out_of_f16_guard(gmax)) atomicOr(p.range_flag, 1u);
-        }
-        LM_TRACE_MARK(3);
-        if (!have_next) break;
-        it = nit;
-        b = nb;
-        y0 = ny0;
-        x0 = nx0;
-        n0 = nn0;
-#pragma unroll
-        for (int j = 0; j < SM::A_PER_WAVE; ++j) voffC[j] = voffN[j];
-        epar ^= 1;
-        lm_barrier_lds();  // buffer 1 (the staging area) is rewritten by the DMA of the new item's chunk 1
-        LM_TRACE_MARK(4);
-    }
-    LM_TRACE_FLUSH();
-}
-
 // The persistent kernel addresses a tensor through a raw buffer descriptor with 32-bit offsets whose top bit marks an
 // out-of-image lane: it serves tensors below 2 GiB with an even number of 16-channel chunks (every level of the network;
 // batches are cut into sub-batches that fit); anything else takes the simple kernel.
@@ -1346,20 +827,10 @@ static hipError_t launch_conv_h3_t(const ConvParamsH3& p, hipStream_t stream) {
             const int n_ct = p.Cout / TN;
             const int xcd_order = order_env >= 0 ? order_env : (n_ct >= 2 && n_ptiles >= 64 ? 1 : 0);
             const int n_items = xcd_order ? 8 * ((n_ptiles + 7) / 8) * n_ct : n_ptiles * n_ct;
-            const unsigned blocks = (unsigned)std::min(n_items, n_cu);
-            // LM_H3_MMA=16 runs the 3x3 convs on the v_mfma_f32_16x16x32_f16 kernel (conv_igemm_h3q).  Measured on MI355X
-            // (profiles/r02o_*): +3 % per layer in isolation on uniform random operands (it clocks higher: less power per FLOP),
-            // -2.6 % in the whole two-lane forward on the network's own, half-zero operands (its 17-cycle issue cadence and the
-            // half-empty fourteenth phase cost 10 % more cycles) -- so the 32x32x16 kernel stays the default.
-            static const bool mma16 = [] { const char* e = getenv("LM_H3_MMA"); return e && e[0] == '1' && e[1] == '6'; }();
-            if (TAPS == 9 && mma16) {
-                if (g16)
-                    LM_LAUNCH((conv_igemm_h3q<true>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
-                else if (pd.head_labels != nullptr)
-                    LM_LAUNCH((conv_igemm_h3q<false, true>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
-                else
-                    LM_LAUNCH((conv_igemm_h3q<false>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
-            } else if (g16)
+            // LM_H3_GRID: lab hook, caps the number of persistent workgroups
+            static const int grid_cap = [] { const char* e = getenv("LM_H3_GRID"); return e ? atoi(e) : 0; }();
+            const unsigned blocks = (unsigned)std::min(n_items, grid_cap > 0 ? std::min(grid_cap, n_cu) : n_cu);
+            if (g16)
                 LM_LAUNCH((conv_igemm_h3p<TAPS, true>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
             else if (TAPS == 9 && pd.head_labels != nullptr)
                 LM_LAUNCH((conv_igemm_h3p<9, false, true>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
@@ -1503,188 +974,6 @@ __global__ __launch_bounds__(256) void upsample2x_h3_kernel(UpsampleParams p) {
     const uint4 hi = {h0.x, h0.y, h1.x, h1.y}, lo = {l0.x, l0.y, l1.x, l1.y};
     *reinterpret_cast<uint4*>(dst) = hi;
     *reinterpret_cast<uint4*>(dst + 16) = lo;
-}
-
-// ---------------------------------------------------------------------------------------------
-// 1x1 conv (at LOW resolution, resunet.py:144-155 commuted, see nn_engine.hip) + bilinear x2 in ONE kernel: the low-resolution
-// result never goes to memory.  Measured motive (tools/bw_tail_ablation.py, profiles/r02zi_*): the bandwidth-bound kernels are NOT
-// hidden by the second forward lane -- under the power budget every byte moved costs matrix clock -- the 1x1 convs and the
-// upsamples were 5.2 ms of a 68 ms forward.
-// A work item is 64 output channels x a tile of 8 x 16 low-resolution cells: it computes the 1x1 conv on the 9 x 17 pixels
-// r0..r0+8, c0..c0+16 (clamped to the image: one row/column of overlap with the next tile; the pixels of a 1x1 conv are
-// independent, so any list of <= 160 of them fills the five N-tiles), rounds through the split format exactly as the stand-alone
-// 1x1 kernel does, parks the tile in LDS in the tensor's own pixel layout, and every cell (i, j) then writes the 2 x 2 output pixels
-// (2i+1..2i+2, 2j+1..2j+2) that depend on the pixels i..i+1, j..j+1 only (plus row/column 0 of the image from the cells of its
-// first row/column) with upsample2x_h3_kernel's own expression: bit-identical to the two kernels it replaces.
-// Five waves, wave = N-tile (both M-tiles of 32 channels).  Operands are staged through LDS 32 input channels at a time with
-// whole-line loads (8 lanes per pixel: a first version that loaded the fragments straight from global memory spent 2.5x the
-// time of the stand-alone 1x1 kernel in the texture addresser: 16 bytes per lane from 32 different lines per instruction); one
-// barrier per stage, the next stage's loads in flight under the matrix instructions.  64 KB of LDS: two workgroups per CU, one
-// in its memory-bound main loop while the other computes and stores its outputs.
-constexpr int UP_TR = 8, UP_TC = 16, UP_NPX = 160, UP_NVALID = (UP_TR + 1) * (UP_TC + 1), UP_PW1 = UP_TC + 1;
-constexpr int UP_PSTR = 272;   // parked tile: 256 B of split data + 16 B pad per pixel
-constexpr int UP_SSTR = 144;   // staged operands: 128 B (32 channels) + 16 B pad per pixel / weight row (conflict-free b128 reads)
-constexpr int UP_STAGE_BYTES = (UP_NPX + 64) * UP_SSTR;
-constexpr int UP_THREADS = 320;
-constexpr int UP_PIECES = (UP_NPX + 64) * 8;                        // 16-byte pieces of a stage
-constexpr int UP_PPT = (UP_PIECES + UP_THREADS - 1) / UP_THREADS;   // per thread
-static_assert(UP_NVALID <= UP_NPX && 2 * UP_STAGE_BYTES >= UP_NPX * UP_PSTR, "the parked tile reuses the operand buffers");
-
-__global__ __launch_bounds__(UP_THREADS) void conv1x1_up2x_h3_kernel(ConvParamsH3 p) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * UP_STAGE_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63, wave = lm_uniform(tid >> 6);
-    const int li = lane & 31, kb = lane >> 5;
-    const int h = p.H, w = p.W;  // low resolution
-    const int n_ct = p.Cout >> 6, tiles_x = (w + UP_TC - 1) / UP_TC, tiles_y = (h + UP_TR - 1) / UP_TR;
-    int it = blockIdx.x;
-    const int ct = it % n_ct;
-    it /= n_ct;
-    const int tx = it % tiles_x;
-    it /= tiles_x;
-    const int ty = it % tiles_y, b = it / tiles_y;
-    const int r0 = ty * UP_TR, c0 = tx * UP_TC, n0 = ct * 64;
-#ifdef LM_LAB_HOOKS  // tools/up2x_lab.py: p.head_C (unused here) selects a timing variant: 1 = no main loop, 2 = no output phase
-    const int lab_variant = p.head_C;
-#else
-    constexpr int lab_variant = 0;
-#endif
-
-    // ---- staging geometry: piece = (row of the stage image, 16-byte slot 0..7); rows 0..159 pixels, 160..223 weight rows
-    const char* gsrc[UP_PPT];
-    int ldst[UP_PPT];
-#pragma unroll
-    for (int k = 0; k < UP_PPT; ++k) {
-        const int piece = tid + k * UP_THREADS;
-        const int row = piece >> 3, slot = piece & 7;
-        ldst[k] = piece < UP_PIECES ? row * UP_SSTR + slot * 16 : -1;
-        if (row < UP_NPX) {
-            const int n = row < UP_NVALID ? row : UP_NVALID - 1;  // padding pixels hold something valid that nobody reads
-            const int pr = n / UP_PW1, pc = n - pr * UP_PW1;
-            const int r = min(r0 + pr, h - 1), c = min(c0 + pc, w - 1);
-            gsrc[k] = p.in + ((((size_t)b * h + r) * w + c) * p.in_cstride + p.in_coff) * 4 + slot * 16;
-        } else {
-            const int co = min(row - UP_NPX, 63);
-            gsrc[k] = p.w + ((size_t)(n0 + co) * p.Cin) * 4 + slot * 16;
-        }
-    }
-    // ---- 1x1 conv: D[cout][pixel] += W[cout][k] * A[k][pixel], three products per 16-channel chunk in the order of conv_igemm_h3p
-    lm_f32x16 acc[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc[m][k] = 0.f;
-    const int nstages = lab_variant == 1 ? 0 : p.Cin >> 5;
-    // (six named registers: as an array or a struct returned from a lambda the compiler kept the staged pieces in scratch memory)
-    static_assert(UP_PPT == 6, "UP_FOR_PIECES lists the pieces by hand");
-#define UP_FOR_PIECES(X) X(0) X(1) X(2) X(3) X(4) X(5)
-#define UP_DECL(k) uint4 piece##k;
-#define UP_FETCH(k) piece##k = *reinterpret_cast<const uint4*>(gsrc[k] + fetch_off);  // (pieces past the end re-read weight row 63)
-#define UP_PUT(k) \
-    if (ldst[k] >= 0) *reinterpret_cast<uint4*>(buf + ldst[k]) = piece##k;
-    UP_FOR_PIECES(UP_DECL)
-    size_t fetch_off = 0;
-    UP_FOR_PIECES(UP_FETCH)
-    const int a_off = (wave * 32 + li) * UP_SSTR + kb * 32, w_off = (UP_NPX + li) * UP_SSTR + kb * 32;
-    for (int s = 0; s < nstages; ++s) {
-        char* buf = lds + (s & 1) * UP_STAGE_BYTES;
-        UP_FOR_PIECES(UP_PUT)
-        __syncthreads();  // (the buffer written at the top of stage s+1 was last read in stage s-1: every thread is past that here)
-        fetch_off = (size_t)min(s + 1, nstages - 1) * 128;  // (the last stage fetches itself again: no branch around the loads)
-        UP_FOR_PIECES(UP_FETCH)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {  // the two 16-channel chunks of the stage
-            lm_h16x8 ah, al, wh, wl;
-            memcpy(&ah, buf + a_off + c * 64, 16);
-            memcpy(&al, buf + a_off + c * 64 + 16, 16);
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                memcpy(&wh, buf + w_off + m * 32 * UP_SSTR + c * 64, 16);
-                memcpy(&wl, buf + w_off + m * 32 * UP_SSTR + c * 64 + 16, 16);
-                acc[m] = lm_mfma_f32_32x32x16_f16(wh, ah, acc[m]);
-                acc[m] = lm_mfma_f32_32x32x16_f16(wh, al, acc[m]);
-                acc[m] = lm_mfma_f32_32x32x16_f16(wl, ah, acc[m]);
-            }
-        }
-    }
-#undef UP_FOR_PIECES
-#undef UP_DECL
-#undef UP_FETCH
-#undef UP_PUT
-    __syncthreads();  // the parked tile overwrites both operand buffers
-    // ---- bias, split, park the tile: accumulator register 4 g4 + k of lane (li, kb) is channel 32 m + 8 g4 + 4 kb + k of pixel li
-    char* stage = lds;
-    unsigned gmax = 0u;
-    {
-        const int n = wave * 32 + li;
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int cl = 32 * m + 8 * g4 + 4 * kb;
-                const float4 bias = *reinterpret_cast<const float4*>(p.bias + n0 + cl);
-                const float v0 = fmaf(acc[m][4 * g4 + 0], p.acc_scale, bias.x), v1 = fmaf(acc[m][4 * g4 + 1], p.acc_scale, bias.y),
-                            v2 = fmaf(acc[m][4 * g4 + 2], p.acc_scale, bias.z), v3 = fmaf(acc[m][4 * g4 + 3], p.acc_scale, bias.w);
-                uint2 ph, plo;
-                lm_split4(v0, v1, v2, v3, &ph, &plo);
-                if (n < UP_NVALID) gmax = lm_pk_absmax_u16(lm_pk_absmax_u16(gmax, ph.x), ph.y);
-                char* d = stage + n * UP_PSTR + (cl >> 3) * 32 + (cl & 7) * 2;
-                *reinterpret_cast<uint2*>(d) = ph;
-                *reinterpret_cast<uint2*>(d + 16) = plo;
-            }
-    }
-    if (p.range_flag != nullptr && lm_pk_out_of_f16_guard(gmax)) atomicOr(p.range_flag, 1u);
-    __syncthreads();
-    // ---- bilinear x2 (align_corners=False): unit = (cell, 8-channel group), group fastest
-    const int H2 = 2 * h, W2 = 2 * w;
-    for (int u = tid; u < (lab_variant == 2 ? 0 : UP_TR * UP_TC * 8); u += UP_THREADS) {
-        const int g = u & 7, cell = u >> 3;
-        const int i = cell / UP_TC, j = cell - i * UP_TC;
-        const int gi = r0 + i, gj = c0 + j;
-        if (gi >= h || gj >= w) continue;
-        float a[2][2][8];  // [row i, i+1][column j, j+1] (clamped by the loader)
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx) load_group(stage + ((i + dy) * UP_PW1 + (j + dx)) * UP_PSTR + g * 32, a[dy][dx]);
-        // output rows: 2gi+1 (weights .75/.25), 2gi+2 (.25/.75, if it exists), and row 0 from the first image row (1/0 on itself)
-#pragma unroll
-        for (int ys = 0; ys < 3; ++ys) {
-            const int y = ys == 0 ? 2 * gi + 1 : (ys == 1 ? 2 * gi + 2 : 0);
-            if (ys == 1 ? y >= H2 : (ys == 2 && gi != 0)) continue;
-            const float wya = ys == 0 ? 0.75f : (ys == 1 ? 0.25f : 1.f), wyb = ys == 0 ? 0.25f : (ys == 1 ? 0.75f : 0.f);
-            const int rb = ys == 2 ? 0 : 1;  // the "yb" row of the expression: the row itself for output row 0
-#pragma unroll
-            for (int xs = 0; xs < 3; ++xs) {
-                const int x = xs == 0 ? 2 * gj + 1 : (xs == 1 ? 2 * gj + 2 : 0);
-                if (xs == 1 ? x >= W2 : (xs == 2 && gj != 0)) continue;
-                const float wxa = xs == 0 ? 0.75f : (xs == 1 ? 0.25f : 1.f), wxb = xs == 0 ? 0.25f : (xs == 1 ? 0.75f : 0.f);
-                const int cb = xs == 2 ? 0 : 1;
-                float o[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) o[k] = wya * (wxa * a[0][0][k] + wxb * a[0][cb][k]) + wyb * (wxa * a[rb][0][k] + wxb * a[rb][cb][k]);
-                char* dst = p.out + ((((size_t)b * H2 + y) * W2 + x) * p.out_cstride + p.out_coff + n0) * 4 + (size_t)g * 32;
-                uint2 h0, l0, h1, l1;
-                lm_split4(o[0], o[1], o[2], o[3], &h0, &l0);
-                lm_split4(o[4], o[5], o[6], o[7], &h1, &l1);
-                const uint4 hi = {h0.x, h0.y, h1.x, h1.y}, lo = {l0.x, l0.y, l1.x, l1.y};
-                *reinterpret_cast<uint4*>(dst) = hi;
-                *reinterpret_cast<uint4*>(dst + 16) = lo;
-            }
-        }
-    }
-}
-
-bool conv1x1_up2x_h3_ok(const ConvParamsH3& p) {
-    return p.bn_s == nullptr && p.border_corr == nullptr && p.pool == nullptr && p.head_labels == nullptr && p.Cout % 64 == 0 && p.Cin % 64 == 0 &&
-           (p.in_cstride & 7) == 0 && (p.in_coff & 7) == 0 && (p.out_cstride & 7) == 0 && (p.out_coff & 7) == 0 && p.H >= 2 && p.W >= 2;
-}
-
-// p describes the 1x1 conv at LOW resolution (H, W = input size); p.out is the [B][2H][2W][out_cstride] tensor
-hipError_t launch_conv1x1_up2x_h3(const ConvParamsH3& p, hipStream_t stream) {
-    if (!conv1x1_up2x_h3_ok(p)) return hipErrorInvalidValue;
-    const unsigned items = (unsigned)p.B * ((p.H + UP_TR - 1) / UP_TR) * ((p.W + UP_TC - 1) / UP_TC) * ((unsigned)p.Cout / 64);
-    LM_LAUNCH(conv1x1_up2x_h3_kernel, dim3(items), dim3(UP_THREADS), 0, stream, p);
-    return hipGetLastError();
 }
 
 hipError_t launch_upsample2x_h3(const UpsampleParams& p, hipStream_t stream) {

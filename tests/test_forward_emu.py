@@ -84,57 +84,3 @@ def test_f16_range_guard_falls_back_to_exact_fp32(emu_engine, golden_dir):
     emu_engine.load_state_dict(0, uo.synthetic_state_dict(3))
     emu_engine.forward(0, x)
     assert emu_engine.model_precision(0) == "split_f16"
-
-
-def test_forward_emulated_16x16x32_kernel(golden_dir):
-    """conv_igemm_h3q (the opt-in 3x3 kernel on v_mfma_f32_16x16x32_f16, LM_H3_MMA=16): the kernel is chosen once per process,
-    so the check runs in a child process -- split-f16 forward of the emulated kernels against the reference golden, and the
-    fused head against the head kernel."""
-    import subprocess
-    import sys
-
-    code = (
-        "import os, sys, numpy as np\n"
-        "sys.path.insert(0, %r)\n"
-        "from lungmask_amd import _native as nat\n"
-        "from lungmask_amd.build import build_emu\n"
-        "from oracle import unet_oracle as uo\n"
-        "g = np.load(os.path.join(%r, 'unet_c3.npz'))\n"
-        "e = nat.Engine(0, nat.Library(build_emu(), allow_emulation=True)); e.load_state_dict(0, uo.synthetic_state_dict(3))\n"
-        "x = g['rand32_x'][:1]\n"
-        "lab, logp = e.forward(0, x)\n"
-        "assert np.abs(logp - g['rand32_logp'][:1]).max() < 1e-3, np.abs(logp - g['rand32_logp'][:1]).max()\n"
-        "bad = lab != g['rand32_lab'][:1]\n"
-        "assert not np.any(bad & (g['rand32_margin'][:1].astype(np.float32) > 2e-3))\n"
-        "assert np.array_equal(e.forward(0, x, want_logp=False)[0], lab)\n"
-        "print('MMA16_OK')\n"
-    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), golden_dir)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500, env=dict(os.environ, LM_H3_MMA="16"))
-    assert "MMA16_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-
-
-def test_fused_conv1x1_upsample_is_bit_identical_to_the_two_kernels(emu_engine, golden_dir, tmp_path):
-    """conv1x1_up2x_h3_kernel against the stand-alone 1x1 conv + upsample kernels (the default; the fused kernel is opt-in, LM_H3_FUSE_UP=1, read once per process: it runs in a child
-    process) on the emulated kernels: identical log-probabilities.  (32 x 32 input: images of 2 x 2 to 16 x 16
-    low-resolution pixels; the larger levels run in the GPU suite.)"""
-    import subprocess
-    import sys
-
-    code = (
-        "import os, sys, numpy as np\n"
-        "sys.path.insert(0, %r)\n"
-        "from lungmask_amd import _native as nat\n"
-        "from lungmask_amd.build import build_emu\n"
-        "from oracle import unet_oracle as uo\n"
-        "g = np.load(os.path.join(%r, 'unet_c3.npz'))\n"
-        "e = nat.Engine(0, nat.Library(build_emu(), allow_emulation=True)); e.load_state_dict(0, uo.synthetic_state_dict(3))\n"
-        "np.save(%r, e.forward(0, g['rand32_x'][:1])[1])\n"
-        "print('FUSED_OK')\n"
-    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), golden_dir, str(tmp_path / "fused.npy"))
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500, env=dict(os.environ, LM_H3_FUSE_UP="1"))
-    assert "FUSED_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-    g = np.load(os.path.join(golden_dir, "unet_c3.npz"))
-    emu_engine.set_precision("split_f16")
-    emu_engine.load_state_dict(0, uo.synthetic_state_dict(3))
-    logp = emu_engine.forward(0, g["rand32_x"][:1])[1]
-    assert np.array_equal(logp, np.load(tmp_path / "fused.npy"))

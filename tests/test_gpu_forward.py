@@ -244,69 +244,3 @@ def test_f16_range_guard_falls_back_to_exact_fp32(gpu_engine):
     gpu_engine.load_state_dict(0, uo.synthetic_state_dict(3))
     gpu_engine.forward(0, x[:1])
     assert gpu_engine.model_precision(0) == "split_f16"
-
-
-def test_forward_16x16x32_kernel_matches_reference_goldens(golden_dir):
-    """conv_igemm_h3q (opt-in, LM_H3_MMA=16: the 3x3 convs on v_mfma_f32_16x16x32_f16).  The kernel is chosen once per process:
-    the parity check against the reference-generated goldens (both class counts, all three input sizes, fused head vs head kernel)
-    runs in a child process."""
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import os, sys, numpy as np\n"
-        "sys.path.insert(0, %r)\n"
-        "from lungmask_amd import _native as nat\n"
-        "from oracle import unet_oracle as uo\n"
-        "e = nat.Engine(0)\n"
-        "for C in (3, 6):\n"
-        "    g = np.load(os.path.join(%r, 'unet_c%%d.npz' %% C)); e.load_state_dict(0, uo.synthetic_state_dict(C))\n"
-        "    for case in ('rand32', 'rand64', 'phantom256'):\n"
-        "        x = g[case + '_x']; lab, logp = e.forward(0, x); ref = g[case + '_logp']\n"
-        "        got = logp if x.shape[-1] <= 64 else logp[:, :, ::4, ::4]\n"
-        "        err = float(np.abs(got - ref).max()); print('C', C, case, 'max|dlogp| %%.3e' %% err)\n"
-        "        assert err < 1e-3, (case, err)\n"
-        "        bad = lab != g[case + '_lab']\n"
-        "        assert not np.any(bad & (g[case + '_margin'].astype(np.float32) > 2e-3))\n"
-        "        assert np.array_equal(e.forward(0, x, want_logp=False)[0], lab)\n"
-        "print('MMA16_OK')\n"
-    ) % (root, golden_dir)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, LM_H3_MMA="16"))
-    print(r.stdout[-1500:])
-    assert "MMA16_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-
-
-def test_fused_conv1x1_upsample_is_bit_identical_to_the_two_kernels(gpu_engine, golden_dir, tmp_path):
-    """conv1x1_up2x_h3_kernel (decoder: up.1 at low resolution + bilinear x2 in one kernel; images of 2 x 2 to 128 x 128
-    low-resolution pixels, image borders, tiles overlapping by one row/column, 3 and 6 classes) against the two kernels it would
-    replace.  The fused kernel is opt-in (LM_H3_FUSE_UP=1, read once per process: it runs in a child process): log-probabilities
-    identical to the last bit."""
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import os, sys, numpy as np\n"
-        "sys.path.insert(0, %r)\n"
-        "from lungmask_amd import _native as nat\n"
-        "from oracle import unet_oracle as uo\n"
-        "e = nat.Engine(0)\n"
-        "out = {}\n"
-        "for C in (3, 6):\n"
-        "    g = np.load(os.path.join(%r, 'unet_c%%d.npz' %% C)); e.load_state_dict(0, uo.synthetic_state_dict(C))\n"
-        "    for case in ('rand32', 'rand64', 'phantom256'):\n"
-        "        out['%%d_%%s' %% (C, case)] = e.forward(0, g[case + '_x'])[1]\n"
-        "np.savez(%r, **out)\n"
-        "print('FUSED_OK')\n"
-    ) % (root, golden_dir, str(tmp_path / "fused.npz"))
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, LM_H3_FUSE_UP="1"))
-    assert "FUSED_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-    ref = np.load(tmp_path / "fused.npz")
-    gpu_engine.set_precision("split_f16")
-    for C in (3, 6):
-        g = np.load(os.path.join(golden_dir, "unet_c%d.npz" % C))
-        gpu_engine.load_state_dict(0, uo.synthetic_state_dict(C))
-        for case in ("rand32", "rand64", "phantom256"):
-            logp = gpu_engine.forward(0, g[case + "_x"])[1]
-            assert np.array_equal(logp, ref["%d_%s" % (C, case)]), (C, case, float(np.abs(logp - ref["%d_%s" % (C, case)]).max()))

@@ -44,7 +44,7 @@ int main(int argc, char** argv) {
                             {32, 1024, 512, false}, {64, 512, 256, false}, {128, 256, 128, false}, {256, 128, 64, false}};
     unsigned* trace = nullptr;
     CK(hipMalloc(&trace, 256 * 8 * 8 * sizeof(unsigned)));
-#ifdef LM_H3_TRACE
+#if defined(LM_H3_TRACE) || defined(LM_H3_TIMELINE)
     CK(hipMemcpyToSymbol(HIP_SYMBOL(lm_h3_trace_ptr), &trace, sizeof(trace)));
 #endif
     char* zeros = nullptr;
@@ -87,6 +87,31 @@ int main(int argc, char** argv) {
         ms /= reps;
         std::vector<unsigned> t(256 * 8 * 8);
         CK(hipMemcpy(t.data(), trace, t.size() * 4, hipMemcpyDeviceToHost));
+#ifdef LM_H3_TIMELINE
+        {   // one more launch, alone, for the timeline of workgroups 0 and LM_TL_WG2: [2][8][256] (id << 28 | clock)
+            CK(hipMemset(trace, 0xff, 2 * 8 * 256 * sizeof(unsigned)));
+            CK(lm::launch_conv3x3_h3(p, 0));
+            CK(hipDeviceSynchronize());
+            std::vector<unsigned> tl(2 * 8 * 256);
+            CK(hipMemcpy(tl.data(), trace, tl.size() * 4, hipMemcpyDeviceToHost));
+            char fn[128];
+            snprintf(fn, sizeof fn, "%s/tl_H%d_Ci%d_Co%d.txt", getenv("LM_TL_DIR") ? getenv("LM_TL_DIR") : ".", s.H, s.Cin, s.Cout);
+            if (FILE* f = fopen(fn, "w")) {
+                for (int wg = 0; wg < 2; ++wg)
+                    for (int w = 0; w < 8; ++w) {
+                        fprintf(f, "wg%d wave%d:", wg, w);
+                        for (int k = 0; k < 256 && tl[(wg * 8 + w) * 256 + k] != 0xffffffffu; ++k)
+                            fprintf(f, " %u:%u", tl[(wg * 8 + w) * 256 + k] >> 28, tl[(wg * 8 + w) * 256 + k] & 0xfffffffu);
+                        fprintf(f, "\n");
+                    }
+                fclose(f);
+            }
+            printf("%-22s %9.4f %9.1f (timeline build)\n", fn, ms, 2.0 * npx * s.Cout * s.Cin * 9 / ms / 1e9);
+            (void)hipFree(in); (void)hipFree(out); (void)hipFree(w); if (pool) (void)hipFree(pool);
+            (void)hipFree(bias); (void)hipFree(bs); (void)hipFree(bt);
+            continue;
+        }
+#endif
         double sum[6] = {0, 0, 0, 0, 0, 0};
         int nw = 0;
         for (int i = 0; i < 256 * 8; ++i) {
