@@ -178,32 +178,29 @@ __device__ __forceinline__ void lm_barrier_lds() { asm volatile("s_waitcnt lgkmc
 #undef LM_H3_TRACE  // the trace reads the shader clock: hardware only
 #endif
 #if defined(LM_H3_TIMELINE) && !defined(LM_EMU_BUILD)
-// Timeline form (lab builds: -DLM_H3_TIMELINE): workgroups 0 and LM_TL_WG2 record (mark id, shader clock) per wave into 8 KiB
-// of LDS (256 events per wave) and copy them to lm_h3_trace_ptr ([2][8][256] unsigned: id << 28 | clock & 0xfffffff) at the end.
+// Timeline form (lab builds: -DLM_H3_TIMELINE): workgroups 0 and LM_TL_WG2 record (mark id, shader clock) per wave into
+// lm_h3_trace_ptr ([2][8][256] unsigned: id << 28 | clock & 0xfffffff; the host presets it to 0xffffffff).
 extern __device__ unsigned* lm_h3_trace_ptr;
 #ifndef LM_TL_WG2
 #define LM_TL_WG2 133
 #endif
-#define LM_TRACE_INIT()                           \
-    constexpr unsigned TLN_ = (G16 || HEAD) ? 128 : 256; \
-    __shared__ unsigned tl_[8][TLN_];             \
-    unsigned tl_n_ = 0;                           \
-    const bool tl_on_ = blockIdx.x == 0 || blockIdx.x == LM_TL_WG2
+#define LM_TRACE_INIT()                                                                                    \
+    unsigned tl_n_ = 0;                                                                                    \
+    const bool tl_on_ = lm_h3_trace_ptr && (blockIdx.x == 0 || blockIdx.x == LM_TL_WG2);                   \
+    unsigned* const tl_o_ = lm_h3_trace_ptr + ((size_t)(blockIdx.x == 0 ? 0 : 1) * 8 + (threadIdx.x >> 6)) * 256
+// (events go straight to global memory from lane 0: the 3x3 form has no LDS left; the stores count in vmcnt, i.e. a wave's
+// DMA wait also waits for its last few trace stores -- a few hundred cycles per chunk of perturbation at most)
 #define LM_TRACE_MARK(K)                                                                                   \
     do {                                                                                                   \
-        if (tl_on_ && tl_n_ < TLN_) {                                                                       \
+        if (tl_on_ && tl_n_ < 256) {                                                                       \
             const unsigned n_ = (unsigned)__builtin_amdgcn_s_memtime();                                    \
-            if ((threadIdx.x & 63) == 0) tl_[threadIdx.x >> 6][tl_n_] = ((unsigned)(K) << 28) | (n_ & 0xfffffffu); \
+            if ((threadIdx.x & 63) == 0) tl_o_[tl_n_] = ((unsigned)(K) << 28) | (n_ & 0xfffffffu);         \
             ++tl_n_;                                                                                       \
         }                                                                                                  \
     } while (0)
 #define LM_TRACE_SUB(K) LM_TRACE_MARK(K)
-#define LM_TRACE_FLUSH()                                                                                   \
-    do {                                                                                                   \
-        if (lm_h3_trace_ptr && tl_on_ && (threadIdx.x & 63) == 0) {                                        \
-            unsigned* o_ = lm_h3_trace_ptr + ((size_t)(blockIdx.x == 0 ? 0 : 1) * 8 + (threadIdx.x >> 6)) * 256; \
-            for (unsigned k_ = 0; k_ < 256; ++k_) o_[k_] = k_ < tl_n_ && k_ < TLN_ ? tl_[threadIdx.x >> 6][k_] : 0xffffffffu; \
-        }                                                                                                  \
+#define LM_TRACE_FLUSH() \
+    do {                 \
     } while (0)
 #elif defined(LM_H3_TRACE)
 extern __device__ unsigned* lm_h3_trace_ptr;
@@ -354,7 +351,38 @@ __device__ __forceinline__ void lm_unsplit4(uint2 hi, uint2 lo, float* out) {
 #define LM_LDS_WAIT8(N, a, b, c, d, e, f, g, h) \
     do {                                        \
     } while (0)
+#define LM_LDS_WAIT5(N, a, b, c, d, e) \
+    do {                               \
+    } while (0)
+#define LM_LDS_WAIT2(N, a, b) \
+    do {                      \
+    } while (0)
+#define LM_LDS_WRITE2_64(ptr, lo8, hi8)                                  \
+    do {                                                                 \
+        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(ptr)) = (lo8); \
+        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(ptr) + 16) = (hi8); \
+    } while (0)
 #else
+// two 8-byte LDS stores of one lane, 16 bytes apart, as ONE hand-issued instruction (counted in lgkmcnt like the reads)
+typedef unsigned lm_u32x2 __attribute__((ext_vector_type(2)));
+#define LM_LDS_WRITE2_64(ptr, lo8, hi8)                                                                                      \
+    do {                                                                                                                     \
+        const lm_u32x2 d0_ = {(lo8).x, (lo8).y}, d1_ = {(hi8).x, (hi8).y};                                                   \
+        asm volatile("ds_write2_b64 %0, %1, %2 offset1:2"                                                                    \
+                     :                                                                                                       \
+                     : "v"((unsigned)(size_t)(__attribute__((address_space(3))) char*)(ptr)), "v"(d0_), "v"(d1_)            \
+                     : "memory");                                                                                            \
+    } while (0)
+#define LM_LDS_WAIT2(N, a, b)                                                                \
+    do {                                                                                     \
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N) : "memory");        \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+    } while (0)
+#define LM_LDS_WAIT5(N, a, b, c, d, e)                                                                            \
+    do {                                                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "i"(N) : "memory");  \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
 #define LM_OPAQUE3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
 #define LM_LDS_WAIT6(N, a, b, c, d, e, f)                                                                         \
     do {                                                                                                          \

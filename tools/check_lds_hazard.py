@@ -93,6 +93,9 @@ for km in re.finditer(r"^(_ZN2lm14conv_igemm_h3[pq]I[^:\n]*):[^\n]*\n(.*?)^\s*s_
                     bad += 1
                 pending.append(dst)
                 continue
+            if op in ("ds_write2_b64", "ds_write_b64", "ds_write_b128") and hand:  # counted in lgkmcnt like the reads; no destination
+                pending.append(set())
+                continue
             if op == "s_waitcnt":
                 m = re.search(r"lgkmcnt\((\d+)\)", ln)
                 if m:

@@ -77,6 +77,24 @@ int main(int argc, char** argv) {
         p.B = B; p.H = s.H; p.W = s.H; p.Cin = s.Cin; p.Cout = s.Cout;
         for (int i = 0; i < 2; ++i) CK(lm::launch_conv3x3_h3(p, 0));
         CK(hipDeviceSynchronize());
+        if (getenv("LM_LAB_VERIFY")) {  // the persistent kernel against the simple 4-wave kernel: outputs must agree bit for bit
+            const size_t ob = npx * s.Cout * 4, pb = s.pool ? npx / 4 * s.Cout * 4 : 0;
+            std::vector<unsigned char> o1(ob), o2(ob), p1(pb), p2(pb);
+            CK(hipMemcpy(o1.data(), out, ob, hipMemcpyDeviceToHost));
+            if (pb) CK(hipMemcpy(p1.data(), pool, pb, hipMemcpyDeviceToHost));
+            CK(hipMemset(out, 0xee, ob));
+            if (pb) CK(hipMemset(pool, 0xee, pb));
+            const int tiles = ((p.W + 15) / 16) * ((p.H + 15) / 16);
+            hipLaunchKernelGGL((lm::conv_igemm_h3<9>), dim3((unsigned)(tiles * p.B), (unsigned)(p.Cout / 64)), dim3(256), (lm::H3Smem<9>::BYTES), 0, p);
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(o2.data(), out, ob, hipMemcpyDeviceToHost));
+            if (pb) CK(hipMemcpy(p2.data(), pool, pb, hipMemcpyDeviceToHost));
+            size_t bad = 0, first = (size_t)-1, badp = 0;
+            for (size_t i = 0; i < ob; ++i) if (o1[i] != o2[i]) { if (!bad) first = i; ++bad; }
+            for (size_t i = 0; i < pb; ++i) badp += p1[i] != p2[i];
+            printf("verify H%d_Ci%d_Co%d: %zu differing output bytes of %zu (first at byte %zu = pixel %zu, byte %zu of its %d), pool: %zu of %zu\n", s.H, s.Cin, s.Cout, bad, ob,
+                   first, first == (size_t)-1 ? 0 : first / (s.Cout * 4), first == (size_t)-1 ? 0 : first % (s.Cout * 4), s.Cout * 4, badp, pb);
+        }
         CK(hipMemset(trace, 0, 256 * 8 * 8 * sizeof(unsigned)));
         CK(hipEventRecord(e0));
         for (int i = 0; i < reps; ++i) CK(lm::launch_conv3x3_h3(p, 0));
