@@ -5,7 +5,7 @@ on the MI355X engine.  Same flags; thin by design (all I/O, off the hot path):
   folders) are read -- and all but DICOM written -- by `volume_io.py` without any imaging dependency;
 * every other format goes through SimpleITK like the reference (imported lazily; this image does not ship it),
   including the DICOM tag carry-over of `--removemetadata`'s complement;
-* `--cpu` is accepted (and logged): there is no CPU path in this engine, the work runs on the MI355X.
+* `--cpu` is an error by default (there is no CPU path in this engine); with LUNGMASK_AMD_ALLOW_CPU_FLAG=1 it is accepted, warned about, and the work runs on the MI355X.
 """
 import argparse
 import os
@@ -34,7 +34,7 @@ def build_parser():
     p.add_argument("--modelname", help="spcifies the trained model, Default: R231", type=str,
                    choices=["R231", "LTRCLobes", "LTRCLobes_R231", "R231CovidWeb"], default="R231")
     p.add_argument("--modelpath", help="spcifies the path to the trained model", default=None)
-    p.add_argument("--cpu", help="Force using the CPU (accepted for compatibility: this engine always runs on the MI355X)", action="store_true")
+    p.add_argument("--cpu", help="Force using the CPU (not available in this engine: an error unless LUNGMASK_AMD_ALLOW_CPU_FLAG=1, then ignored with a warning)", action="store_true")
     p.add_argument("--nopostprocess", help="Deactivates postprocessing (removal of unconnected components and hole filling)", action="store_true")
     p.add_argument("--batchsize", type=int, help="Number of slices processed simultaneously.", default=20)
     p.add_argument("--noprogress", action="store_true", help="If set, no tqdm progress bar will be shown")

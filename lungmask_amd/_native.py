@@ -206,6 +206,8 @@ class Engine:
 
     def stream_handle(self) -> int:
         """hipStream_t of the engine as an integer (0 under emulation): see lm_engine_stream in include/lungmask_hip.h."""
+        if not hasattr(self.L.lib, "lm_engine_stream"):  # an older build of the library: the documented fall-back (host syncs)
+            return 0
         return int(self.L.lib.lm_engine_stream(self.h) or 0)
 
     # -- one rank per engine: the RCCL communicator behind the C ABI (include/lungmask_hip.h: lm_dist_*)

@@ -97,6 +97,8 @@ class ShardedPipeline:
         self.rank = dist.get_rank() if dist is not None else 0
         self.sharded_post = bool(sharded_post)
         self._buf = {}
+        self._slab_caps = {}   # agreed capacity (ints) of the variable-length table exchange of every protocol round
+        self.collectives = 0   # collectives issued for variable-length tables (tests / tools/slab_timing.py read it)
         # the engine's stream as torch's current stream (see the module docstring); None on the CPU / under emulation
         self._stream = None
         if self.device.type == "cuda" and engine.stream_handle():
@@ -138,25 +140,61 @@ class ShardedPipeline:
         sp = (C.c_int * max(len(spare), 1))(*[int(v) for v in spare])
         e.L.check(lib.lm_slab_begin(e.h, lab_slab.data_ptr(), n_r, h, w, self.rank, self.world, int(z0), int(n_total), sp, len(spare), int(skip_below)),
                   "lm_slab_begin")
+        rnd = 0
         while True:
             n = int(lib.lm_slab_pending(e.h))
             if n < 0:
                 raise RuntimeError("lm_slab_pending: no slab post-processing in progress")
-            if self.dist is not None and lib.lm_slab_pending_uniform(e.h):
-                lens = [n] * self.world  # face planes: the same length on every rank, no need to exchange it
-            elif self.dist is not None:
-                lens_t = self._tensor("slab_lens", (self.world,), torch.int64)
-                self._all_gather(lens_t, torch.tensor([n], dtype=torch.int64, device=self.device))
-                lens = [int(v) for v in lens_t.cpu().tolist()]
+            hdr = 0  # ints in front of every rank's table inside the gathered buffer
+            if self.dist is None:
+                lens, stride = [n], n
+                mine = self._tensor("slab_mine", (max(stride, 1),), torch.int32)
+                gathered = mine
+                e.L.check(lib.lm_slab_emit(e.h, mine.data_ptr()), "lm_slab_emit")
+            elif lib.lm_slab_pending_uniform(e.h):
+                lens, stride = [n] * self.world, n  # face planes: the same length on every rank, no need to exchange it
+                mine = self._tensor("slab_mine", (max(stride, 1),), torch.int32)
+                gathered = self._tensor("slab_all", (self.world * max(stride, 1),), torch.int32)
+                e.L.check(lib.lm_slab_emit(e.h, mine.data_ptr()), "lm_slab_emit")
+                if stride:
+                    self._all_gather(gathered, mine)
             else:
-                lens = [n]
-            stride = max(lens)
-            mine = self._tensor("slab_mine", (max(stride, 1),), torch.int32)
-            gathered = self._tensor("slab_all", (self.world * max(stride, 1),), torch.int32) if self.dist is not None else mine
-            e.L.check(lib.lm_slab_emit(e.h, mine.data_ptr()), "lm_slab_emit")
-            if stride and self.dist is not None:
-                self._all_gather(gathered, mine)
-            status = e.L.check(lib.lm_slab_step(e.h, gathered.data_ptr(), stride, (C.c_int64 * self.world)(*lens)), "lm_slab_step")
+                # variable-length tables: every rank sends [length | table | padding] of ONE agreed size, so the lengths travel
+                # inside the table exchange (6 collectives per volume instead of 9).  The agreed capacity of round `rnd` is what
+                # the previous volume needed plus a quarter -- every rank saw the same lengths, so every rank holds the same
+                # number; the first volume (and a table that outgrows the capacity, which every rank notices at the same
+                # time) exchanges the lengths first, as before.
+                cap = self._slab_caps.get(rnd, 0)
+                lens = lens_known = None
+                if cap > 0:
+                    mine = self._tensor("slab_mine", (cap + 1,), torch.int32)
+                    gathered = self._tensor("slab_all", (self.world * (cap + 1),), torch.int32)
+                    mine[:1].fill_(n)
+                    if n <= cap:
+                        e.L.check(lib.lm_slab_emit(e.h, mine.data_ptr() + 4), "lm_slab_emit")
+                    self._all_gather(gathered, mine)
+                    self.collectives += 1
+                    got = [int(v) for v in gathered.view(self.world, cap + 1)[:, 0].cpu().tolist()]
+                    if max(got) <= cap:
+                        lens, stride, hdr = got, cap + 1, 1
+                    else:
+                        lens_known = got  # somebody's table did not fit: exchange again at the exact size
+                if lens is None:
+                    if lens_known is None:
+                        lens_t = self._tensor("slab_lens", (self.world,), torch.int64)
+                        self._all_gather(lens_t, torch.tensor([n], dtype=torch.int64, device=self.device))
+                        lens_known = [int(v) for v in lens_t.cpu().tolist()]
+                        self.collectives += 1
+                    lens, stride = lens_known, max(lens_known)
+                    mine = self._tensor("slab_mine", (max(stride, 1),), torch.int32)
+                    gathered = self._tensor("slab_all", (self.world * max(stride, 1),), torch.int32)
+                    e.L.check(lib.lm_slab_emit(e.h, mine.data_ptr()), "lm_slab_emit")
+                    if stride:
+                        self._all_gather(gathered, mine)
+                        self.collectives += 1
+                self._slab_caps[rnd] = -(-(max(lens) + max(lens) // 4 + 256) // 1024) * 1024
+            status = e.L.check(lib.lm_slab_step(e.h, gathered.data_ptr() + 4 * hdr, stride, (C.c_int64 * self.world)(*lens)), "lm_slab_step")
+            rnd += 1
             if status == 1:
                 return
 
@@ -205,15 +243,20 @@ class ShardedPipeline:
             e.L.check(lib.lm_forward_batches_dev(e.h, self.slot, xf.data_ptr(), n_r, oh, ow, self.batch_size, lab_loc.data_ptr()), "lm_forward_batches_dev")
         if self._stream is None:
             e.sync()
-        with self._on_engine_stream():
-            out = self.assemble(n_total, h, w)
-        if self._stream is not None:
-            self._stream.synchronize()  # the result is complete when this returns (as before)
-        return out
+        return self.assemble(n_total, h, w)
 
     def assemble(self, n_total: int, h: int, w: int) -> torch.Tensor:
         """Everything after the argmax: volume post-processing of the label shards in `shard_buffers(n_total)`, un-crop with
-        the shard's bounding boxes, and the all-gather of the [n_total,h,w] result."""
+        the shard's bounding boxes, and the all-gather of the [n_total,h,w] result.  Safe to call on its own: it makes the
+        engine's stream torch's current stream for its collectives (so they are ordered with the engine's kernels whatever
+        stream the caller had current) and the result is complete when it returns."""
+        with self._on_engine_stream():
+            out = self._assemble(n_total, h, w)
+        if self._stream is not None:
+            self._stream.synchronize()
+        return out
+
+    def _assemble(self, n_total: int, h: int, w: int) -> torch.Tensor:
         e, lib = self.e, self.e.L.lib
         bounds, bbox, lab_all, lab_loc = self.shard_buffers(n_total)
         counts = [bounds[r + 1] - bounds[r] for r in range(self.world)]

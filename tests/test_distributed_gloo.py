@@ -62,10 +62,20 @@ def _worker(rank, world, port, n_total, outdir, mode):
             lab_loc[:n_r] = torch.from_numpy(lab[b[rank] : b[rank + 1]])
             bbox[:n_r] = torch.from_numpy(boxes[b[rank] : b[rank + 1]])
             np.save(os.path.join(outdir, f"asm{int(sharded)}_{rank}.npy"), pipe.assemble(n_total, 96, 80).numpy().copy())
-        # the exchange protocol with a fusion-style spare label
-        slab = torch.from_numpy(lab[b[rank] : b[rank + 1]].copy())
-        pipe.postprocess_slab(slab, b[rank], n_total, spare=(4,))
-        np.save(os.path.join(outdir, f"slab{rank}.npy"), slab.numpy())
+        # the exchange protocol with a fusion-style spare label, three volumes through ONE pipeline object: the first exchanges the
+        # lengths of its three variable-size tables separately (6 collectives), the second carries them in the tables' headers
+        # (3), the third finds every agreed capacity too small and repeats each exchange at the exact size (6)
+        pipe = ShardedPipeline(eng, resolution=(32, 32), dist=dist, device="cpu", sharded_post=True)
+        counts = []
+        for rep in range(3):
+            slab = torch.from_numpy(lab[b[rank] : b[rank + 1]].copy())
+            if rep == 2:
+                pipe._slab_caps = {k: 1 for k in pipe._slab_caps}
+            c0 = pipe.collectives
+            pipe.postprocess_slab(slab, b[rank], n_total, spare=(4,))
+            counts.append(pipe.collectives - c0)
+            np.save(os.path.join(outdir, f"slab{rep}_{rank}.npy"), slab.numpy())
+        np.save(os.path.join(outdir, f"counts{rank}.npy"), np.asarray(counts))
     dist.barrier()
     dist.destroy_process_group()
     eng.close()
@@ -120,8 +130,12 @@ def test_multi_rank_gloo_assemble_and_slab_protocol(tmp_path, world, n_total):
     for sharded in (0, 1):
         for r in range(world):
             assert np.array_equal(np.load(tmp_path / f"asm{sharded}_{r}.npy"), expect), (sharded, r)
-    got = np.concatenate([np.load(tmp_path / f"slab{r}.npy") for r in range(world)])
-    assert np.array_equal(got, po.postprocessing(lab.copy(), spare=[4]))
+    expect_slab = po.postprocessing(lab.copy(), spare=[4])
+    for rep in range(3):
+        got = np.concatenate([np.load(tmp_path / f"slab{rep}_{r}.npy") for r in range(world)])
+        assert np.array_equal(got, expect_slab), rep
+    for r in range(world):
+        assert np.load(tmp_path / f"counts{r}.npy").tolist() == [6, 3, 6], r
 
 
 def test_native_dist_world_of_one_and_argument_checks(emu_engine):

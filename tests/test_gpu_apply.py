@@ -133,12 +133,13 @@ def reference_testvol(golden_dir):
     return np.load(os.path.join(golden_dir, "testvol.npz"))["vol"]
 
 
-def test_real_weights_golden_counts_r231(gpu_engine, reference_testvol):
+def test_real_weights_golden_counts_r231(gpu_engine, reference_testvol, monkeypatch):
     """The reference's own end-to-end known answers (tests/test_mask.py:30-47), written as the reference writes them --
     force_cpu=True included -- against the pretrained R231 weights.  Opt-in: runs when $LUNGMASK_WEIGHTS_DIR holds the .pth."""
     from lungmask_amd import LMInferer
 
     wd = _weights_dir_with("unet_r231-d5d2fc3d.pth")
+    monkeypatch.setenv("LUNGMASK_AMD_ALLOW_CPU_FLAG", "1")  # the reference's tests pass force_cpu=True
     inferer = LMInferer(force_cpu=True, tqdm_disable=True)
     res = inferer.apply(reference_testvol)
     assert np.all(np.unique(res, return_counts=True)[1] == [423000, 64752, 36536])
@@ -148,31 +149,38 @@ def test_real_weights_golden_counts_r231(gpu_engine, reference_testvol):
     assert np.all(np.unique(res, return_counts=True)[1] == [423000, 64752, 36536])
 
 
-def test_real_weights_golden_counts_fused(gpu_engine, reference_testvol):
+def test_real_weights_golden_counts_fused(gpu_engine, reference_testvol, monkeypatch):
     """tests/test_mask.py:50-61: LTRCLobes filled by R231."""
     from lungmask_amd import LMInferer
 
     _weights_dir_with("unet_r231-d5d2fc3d.pth", "unet_ltrclobes-3a07043d.pth")
+    monkeypatch.setenv("LUNGMASK_AMD_ALLOW_CPU_FLAG", "1")
     inferer = LMInferer(modelname="LTRCLobes", force_cpu=True, fillmodel="R231", tqdm_disable=True)
     res = inferer.apply(reference_testvol)
     assert np.all(np.unique(res, return_counts=True)[1] == [423000, 13334, 23202, 23834, 40918])
 
 
-def test_force_cpu_is_accepted(gpu_engine, tmp_path, monkeypatch):
-    """force_cpu=True (every end-to-end test of the reference passes it) is accepted and logged, the engine still runs on the
-    GPU; LUNGMASK_AMD_STRICT_CPU=1 makes it an error."""
+def test_force_cpu_raises_unless_opted_in(gpu_engine, tmp_path, monkeypatch):
+    """force_cpu=True is a hard device selection in the reference (mask.py:118-134).  This engine has no CPU path: the request is an
+    error by default; LUNGMASK_AMD_ALLOW_CPU_FLAG=1 (what code written against the reference sets -- its own end-to-end tests pass
+    force_cpu=True) accepts the flag with a warning and runs on the GPU.  `out=` / `reuse_output` deliver the labels without a copy."""
     from lungmask_amd import LMInferer
 
     p = tmp_path / "unet_synth.pth"
     sd = uo.synthetic_state_dict(3)
     torch.save(sd, p)
     vol = po.phantom(2, 512, 512, seed=5)
-    a = LMInferer(modelpath=str(p), force_cpu=True, tqdm_disable=True).apply(vol)
-    b = LMInferer(modelpath=str(p), tqdm_disable=True).apply(vol)
-    assert np.array_equal(a, b)
-    monkeypatch.setenv("LUNGMASK_AMD_STRICT_CPU", "1")
+    monkeypatch.delenv("LUNGMASK_AMD_ALLOW_CPU_FLAG", raising=False)
     with pytest.raises(RuntimeError):
         LMInferer(modelpath=str(p), force_cpu=True)
+    monkeypatch.setenv("LUNGMASK_AMD_ALLOW_CPU_FLAG", "1")
+    a = LMInferer(modelpath=str(p), force_cpu=True, tqdm_disable=True).apply(vol)
+    inf = LMInferer(modelpath=str(p), tqdm_disable=True, reuse_output=True)
+    b = inf.apply(vol)
+    assert a.dtype == np.uint8 and b.dtype == np.uint8 and np.array_equal(a, b)
+    assert inf.apply(vol) is b  # the reused buffer
+    mine = np.empty(vol.shape, np.uint8)
+    assert inf.apply(vol, out=mine) is mine and np.array_equal(mine, a)
 
 
 def test_sharded_pipeline_world1_on_torch_cuda_tensors(gpu_engine):
