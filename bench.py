@@ -35,23 +35,40 @@ CONFIGS = {  # BASELINE.json configs[1..3]
 }
 
 
+PMC_PIN = os.path.join(ROOT, "profiles", "pmc_current.json")  # written by tools/summarize_prof.py --pin
+
+
+def _sha256(path):
+    import hashlib
+
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
 def pmc_traffic(kernel_substr):
     """HBM bytes per launch of the dominant kernel, launch-weighted over every instantiation whose name contains
-    `kernel_substr`, from the LATEST COMMITTED rocprofv3 PMC summary of this same command (tools/summarize_prof.py ->
-    profiles/rNN_pmc.json).  It is read from that file, not measured in this run; (None, None) when there is no summary."""
-    import glob
-
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
-    if not files:
-        return None, None
-    d = json.load(open(files[-1]))
+    `kernel_substr`, from the ONE committed rocprofv3 PMC summary that profiles/pmc_current.json names (file, the commit
+    it was measured on, sha256 of the kernel sources at that time).  It is read from that file, not measured in this run.
+    Returns (bytes | None, provenance string): None when there is no pinned summary or when the conv kernel's sources
+    have changed since it was taken (a stale number is refused, not reported)."""
+    if not os.path.exists(PMC_PIN):
+        return None, "no pinned PMC summary (profiles/pmc_current.json)"
+    pin = json.load(open(PMC_PIN))
+    path = os.path.join(ROOT, "profiles", pin["file"])
+    if not os.path.exists(path):
+        return None, f"pinned PMC summary profiles/{pin['file']} is missing"
+    for rel, want in pin.get("sources_sha256", {}).items():
+        if not os.path.exists(os.path.join(ROOT, rel)) or _sha256(os.path.join(ROOT, rel)) != want:
+            return None, (f"REFUSED: {rel} has changed since profiles/{pin['file']} was measured (commit {pin.get('commit', '?')}); "
+                          "re-run the PMC passes (tools/gpu_round_check.sh TAG pmc; tools/summarize_prof.py ... --pin)")
+    d = json.load(open(path))
     tot = n = 0.0
     for k, v in d.get("kernels", {}).items():
         if kernel_substr in k and "hbm_bytes_per_launch_corrected" in v:
             w = float(v.get("launches_FETCH_SIZE", 1))
             tot += v["hbm_bytes_per_launch_corrected"] * w
             n += w
-    return (tot / n if n else None), os.path.relpath(files[-1], ROOT)
+    return (tot / n if n else None), f"profiles/{pin['file']} (measured on commit {pin.get('commit', '?')}, kernel sources unchanged since)"
 
 
 def cpu_baseline(n_sample, sd):
@@ -90,6 +107,82 @@ def cpu_baseline(n_sample, sd):
     }
 
 
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n, emu):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, LOCAL_RANK = device),
+    exactly the environment `python -m torch.distributed.run --nproc-per-node N` would give them.  Rank 0 inherits stdout
+    (the JSON line); the exit status is the worst of the ranks'."""
+    import subprocess
+
+    if not emu:
+        import torch
+
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this machine -- refusing to report a {have}-GPU number as a "
+                             f"{n}-GPU one (BASELINE config 5 needs an {n}-GPU node)")
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), LM_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = [p.wait() for p in procs]
+    raise SystemExit(max(abs(rc) for rc in rcs))
+
+
+class NativeGroup:
+    """`--dist native`: every collective of the job -- the pipeline's all-gathers AND the bench's own barrier / max-over-ranks
+    -- goes through the engine's RCCL communicator behind the C ABI (lm_dist_*); torch.distributed is not initialised, a
+    TCPStore only hands the ncclUniqueId to the ranks."""
+
+    def __init__(self, eng, rank, world, device):
+        import datetime
+
+        import torch
+        import torch.distributed as td
+
+        from lungmask_amd.pipeline import NativeDist
+
+        self.torch, self.dev = torch, device
+        store = td.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29533")), world, rank == 0,
+                            timeout=datetime.timedelta(seconds=120))
+        uid = NativeDist.exchange_id(eng, rank, store) if world > 1 else None
+        self.nd = NativeDist(eng, rank, world, uid)
+        self.eng = eng
+        self._one = torch.zeros(1, dtype=torch.float64, device=device)
+        self._all = torch.zeros(world, dtype=torch.float64, device=device)
+
+    def gather_f64(self, v):
+        self._one.fill_(float(v))
+        self.torch.cuda.synchronize()
+        self.nd.all_gather_into_tensor(self._all, self._one)
+        self.eng.sync()
+        return [float(x) for x in self._all.cpu().tolist()]
+
+    def barrier(self):
+        self.gather_f64(0.0)
+
+    def max(self, v):
+        return max(self.gather_f64(v))
+
+    def world_size(self):
+        return int(self.eng.L.lib.lm_dist_world(self.eng.h))
+
+    def destroy(self):
+        self.nd.destroy()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,19 +194,33 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="split_f16", choices=["split_f16", "f32"])
     ap.add_argument("--post", default="slab", choices=["slab", "gathered"], help="N>1 post-processing: slab-sharded (default) or label all-gather + redundant whole-volume pass")
+    ap.add_argument("--dist", default="torch", choices=["torch", "native"],
+                    help="N>1 collectives: torch.distributed (backend nccl = RCCL) or the engine's own RCCL communicator behind the C ABI (lm_dist_*)")
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2], help="forward lanes (2: consecutive batches overlap on two streams)")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4], help="BASELINE.json configuration: 2 R231 (the headline), 3 LTRCLobes, 4 LTRCLobes_R231 fused")
-    ap.add_argument("--host-steps", type=int, default=3, help="untimed-by-the-contract extra steps numpy -> numpy (lm_apply_host) for value_host_to_host; 0 to skip")
+    ap.add_argument("--host-steps", type=int, default=-1,
+                    help="steps of the two numpy -> numpy measurements beside `value` (lm_apply_host and LMInferer.apply); default: --steps, 0 to skip")
     args = ap.parse_args()
     cfg_name, n_classes, fill_classes = CONFIGS[args.config]
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and args.config != 2:
         raise SystemExit("configs 3 and 4 are single-GPU configurations (BASELINE.json)")
+    if args.host_steps < 0:
+        args.host_steps = args.steps
+    # TEST HOOK (tests/test_bench_spawn.py, CPU suite): LM_BENCH_EMU=1 runs this same script on the g++ emulation of the kernels
+    # over gloo with a tiny volume, to drive the spawn / sharding / reporting logic where there is no GPU.  The line it prints
+    # says so in `data`; nothing else reads the variable.
+    emu = os.environ.get("LM_BENCH_EMU") == "1"
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus, emu)  # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus N` or "
+                         f"`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
 
     import torch
 
@@ -121,19 +228,37 @@ def main():
     from lungmask_amd import synthetic as po  # phantom + seeded stand-in weights (no oracle code in the timed job)
     uo = po
 
-    dist = None
-    # LM_BENCH_FORCE_DIST=1: take the multi-GPU code path (RCCL process group, ShardedPipeline) with a world of one,
+    if not emu and (not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank):
+        raise SystemExit(f"rank {rank}: no GPU cuda:{local_rank} on this machine ({torch.cuda.device_count() if torch.cuda.is_available() else 0} visible); "
+                         "lungmask_amd has no CPU path")
+    dist = None    # torch.distributed, when it carries the collectives
+    group = None   # NativeGroup, when the engine's own communicator does
+    # LM_BENCH_FORCE_DIST=1: take the multi-GPU code path (RCCL communicator, ShardedPipeline) with a world of one,
     # which is how that path is smoke-tested on a 1-GPU box
     use_dist = world > 1 or os.environ.get("LM_BENCH_FORCE_DIST") == "1"
-    if use_dist:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if use_dist and args.dist == "torch":
         import torch.distributed as dist
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if emu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    eng = nat.Engine(local_rank)  # raises if liblungmask_hip.so or the GPU is missing: no fallback
+    if emu:
+        from lungmask_amd.build import build_emu
+
+        eng = nat.Engine(0, nat.Library(build_emu(), allow_emulation=True))
+    else:
+        eng = nat.Engine(local_rank)  # raises if liblungmask_hip.so or the GPU is missing: no fallback
+    dev = torch.device("cpu") if emu else torch.device("cuda", local_rank)
+    if use_dist and args.dist == "native":
+        if emu:
+            raise SystemExit("--dist native needs RCCL (no emulation of it)")
+        torch.cuda.set_device(local_rank)
+        group = NativeGroup(eng, rank, world, dev)
     wd = os.environ.get("LUNGMASK_WEIGHTS_DIR")
     pth = {3: "unet_r231-d5d2fc3d.pth", 6: "unet_ltrclobes-3a07043d.pth"}
 
@@ -144,7 +269,7 @@ def main():
 
     sd, weights = load(n_classes)
     eng.load_state_dict(0, sd)
-    fill_slot = -1
+    fill_slot, sd_fill = -1, None
     if fill_classes is not None:
         sd_fill, w2 = load(fill_classes)
         eng.load_state_dict(1, sd_fill)
@@ -154,15 +279,23 @@ def main():
     eng.set_streams(args.streams)
 
     n_local, n_total = args.slices, args.slices * world
-    vol = po.phantom(n_total, 512, 512, z0=rank * n_local, z1=(rank + 1) * n_local)
+    hw, res = ((96, 80), (32, 32)) if emu else ((512, 512), (256, 256))
+    vol = po.phantom(n_total, hw[0], hw[1], z0=rank * n_local, z1=(rank + 1) * n_local)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        elif group is not None:
+            group.barrier()
 
     def sync_all():
         eng.sync()
         if torch.cuda.is_available():
             torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+        if dist is not None or group is not None:
+            barrier()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
 
     if not use_dist:
         vd = eng.to_device(vol)
@@ -173,9 +306,9 @@ def main():
     else:
         from lungmask_amd.pipeline import ShardedPipeline
 
-        dev = torch.device("cuda", local_rank)
         vt = torch.from_numpy(vol).to(dev)
-        pipe = ShardedPipeline(eng, slot=0, batch_size=args.batch, dist=dist, device=dev, sharded_post=args.post == "slab")
+        pipe = ShardedPipeline(eng, slot=0, batch_size=args.batch, resolution=res, dist=dist if dist is not None else group.nd, device=dev,
+                               sharded_post=args.post == "slab")
 
         def step():
             pipe.apply_shard(vt, n_total)
@@ -191,9 +324,11 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    elif group is not None:
+        dt = group.max(dt)
     stats = eng.profile_read()
     eng.profile(False)
     post_info = eng.postprocess_info()
@@ -211,11 +346,14 @@ def main():
     if args.streams == 1:
         stats = stats or solo
 
-    # numpy in -> numpy out (lm_apply_host: H2D of the volume, the same hot path, D2H of the labels): what a caller of
-    # LMInferer.apply(ndarray) sees.  Reported beside `value`, never as `value` (the timed region above starts with the
-    # volume resident in HBM).
-    host = None
-    if not use_dist and args.host_steps > 0:
+    # numpy in -> numpy out: what a caller of the drop-in sees (SURVEY.md section 8d defines the metric on a host volume).  Two forms,
+    # both over --steps steps like `value`, both reported beside `value`, never as `value` (the contract's timed region starts with
+    # the volume resident in HBM): the C-ABI call lm_apply_host with a caller-owned, reused output array, and LMInferer.apply
+    # itself -- the class a user of the reference calls -- with the reference's semantics (a FRESH result array per call) and
+    # with reuse_output=True.
+    host = lmi = None
+    if not use_dist and args.host_steps > 0 and not emu:
+        ref_labels = od.download()
         res_h = eng.apply(0, vol, fill_slot=fill_slot, batch_size=args.batch)
         eng.sync()
         t0h = time.perf_counter()
@@ -224,7 +362,23 @@ def main():
         dth = (time.perf_counter() - t0h) / args.host_steps
         host = {"value": round(n_total / dth, 2), "unit": "slices/s", "ms_per_step": round(dth * 1e3, 3), "steps": args.host_steps,
                 "note": "numpy int16 volume in pageable host memory -> uint8 numpy labels in a caller-owned, reused host array (lm_apply_host), PCIe copies included; "
-                        "identical labels: " + str(bool(np.array_equal(res_h, od.download())))}
+                        "identical labels: " + str(bool(np.array_equal(res_h, ref_labels)))}
+        from lungmask_amd.mask import LMInferer
+
+        lmi = {}
+        for key, reuse in (("fresh_output_per_call", False), ("reuse_output", True)):
+            inf = LMInferer(modelname="R231" if n_classes == 3 else "LTRCLobes", fillmodel="R231" if fill_classes else None, batch_size=args.batch,
+                            device_id=local_rank, precision=args.precision, reuse_output=reuse, state_dict=sd, fill_state_dict=sd_fill, engine=eng)
+            r = inf.apply(vol)
+            t0h = time.perf_counter()
+            for _ in range(args.host_steps):
+                r = inf.apply(vol)
+            dth = (time.perf_counter() - t0h) / args.host_steps
+            lmi[key] = {"value": round(n_total / dth, 2), "ms_per_step": round(dth * 1e3, 3), "identical_labels": bool(np.array_equal(r, ref_labels))}
+        lmi.update({"unit": "slices/s", "steps": args.host_steps,
+                    "note": "lungmask_amd.LMInferer.apply(ndarray int16 [300,512,512]) -> ndarray uint8, the drop-in call itself (mask.py:212-232): "
+                            "fresh_output_per_call = the reference's semantics (a new 79 MB array per call: page faults + unmapping on top of the PCIe "
+                            "copies); reuse_output = LMInferer(reuse_output=True)"})
 
     if rank == 0:
         value = n_total * args.steps / dt
@@ -262,7 +416,7 @@ def main():
                 "traffic": traffic,
                 "traffic_unit": "HBM bytes/launch, launch-weighted over the same 17 launches per batch as algorithmic_bytes_per_launch; NOT measured in this "
                                 f"run: read from the committed rocprofv3 PMC summary {traffic_src} (separate FETCH_SIZE / WRITE_SIZE passes of "
-                                "`bench.py --streams 1`, gfx950-corrected)" if traffic is not None else "no committed PMC summary",
+                                "`bench.py --streams 1`, gfx950-corrected)" if traffic is not None else traffic_src,
                 "algorithmic_bytes_per_launch": conv["bytes"] / conv["launches"],
                 "launches": conv["launches"],
                 "avg_launch_ms": round(conv["total_ms"] / conv["launches"], 4),
@@ -278,6 +432,8 @@ def main():
             "value": round(value, 2),
             "unit": "slices/s",
             "n_gpus": world,
+            "collective_world": (dist.get_world_size() if dist is not None else group.world_size()) if use_dist else 1,
+            "collectives": (("torch.distributed/" + ("gloo" if emu else "nccl(RCCL)")) if dist is not None else "lm_dist_* (engine-owned RCCL communicator)") if use_dist else None,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -285,22 +441,25 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f16x3-split (hi/lo f16 operands, f32 accumulate; fp32-class)" if h3 else "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not emu else "EMULATION TEST HOOK (LM_BENCH_EMU=1): g++ emulation of the kernels on the CPU, tiny volume -- not a measurement",
             "config": {
-                "workload": f"BASELINE.json configs[{args.config - 1}]: {cfg_name}, 512x512x{n_local} int16 HU phantom per GPU ({n_total} slices total), "
+                "workload": f"BASELINE.json configs[{args.config - 1}]: {cfg_name}, {hw[0]}x{hw[1]}x{n_local} int16 HU phantom per GPU ({n_total} slices total), "
                             f"batchsize={args.batch}, LMInferer.apply device-resident (pre + forward + argmax + 3-D post + un-crop"
                             + (" + second model + fusion + full-resolution post" if fill_slot >= 0 else "") + ")",
                 "weights": weights,
                 "parallelism": "single GPU" if not use_dist else (f"slice-sharded x{world}: slab-local post-processing + 6 small RCCL table all-gathers, 1 all-gather of the output" if args.post == "slab" else f"slice-sharded x{world}: RCCL all-gather of the labels, redundant whole-volume post-processing, all-gather of the output"),
             },
             "end_to_end_tflops": round(value * (FLOP_PER_SLICE[n_classes] + (FLOP_PER_SLICE[fill_classes] if fill_classes else 0.0)) / 1e12, 2),
+            "value_definition": "`value` = device-resident (contract: inputs in HBM when the timed region starts); value_host_to_host / "
+                                "value_lminferer_apply = the same step numpy -> numpy over the same number of steps (SURVEY 8d's definition)",
             "value_host_to_host": host,
+            "value_lminferer_apply": lmi,
             "roofline": roof,
             "stages_ms_per_step": {s["name"]: round(s["total_ms"], 3) for s in solo},
             "stages_note": "HIP-event time per kernel kind of ONE step, from the untimed single-lane pass after the timed region",
             "postprocessing": post_info,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not emu:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, sd)
     # The JSON line must be the LAST line of the job's stdout: RCCL prints a version banner through C stdio, which is
     # block-buffered on a pipe and would otherwise be flushed at exit, after Python's own output -- on every rank.
@@ -311,6 +470,10 @@ def main():
         libc.fflush(None)
         dist.barrier()
         dist.destroy_process_group()
+    elif group is not None:
+        libc.fflush(None)
+        group.barrier()
+        group.destroy()
     libc.fflush(None)
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -60,6 +60,9 @@ class LMInferer:
         device_id: int = 0,
         precision: str = "split_f16",
         reuse_output: bool = False,
+        state_dict=None,
+        fill_state_dict=None,
+        engine=None,
     ):
         assert modelname in MODEL_URLS, "Modelname not found. Please choose from: {}".format(MODEL_URLS.keys())  # mask.py:95-97
         if fillmodel is not None:
@@ -90,12 +93,15 @@ class LMInferer:
                     "lungmask_amd is an MI355X-only engine: force_cpu=True / --cpu is not available (use the reference package for CPU, "
                     "or set LUNGMASK_AMD_ALLOW_CPU_FLAG=1 to accept the flag and run on the GPU)")
             logger.warning("force_cpu requested and LUNGMASK_AMD_ALLOW_CPU_FLAG=1: lungmask_amd has no CPU path, running on the MI355X")
-        self.engine = _native.Engine(device_id)
+        # Extensions (not in the reference): `state_dict` / `fill_state_dict` = weights that are already in memory (what the
+        # deprecated `apply(image, model)` shim and bench.py pass) instead of a file or download; `engine` = an existing
+        # _native.Engine to load them into instead of a new one (one engine owns ~5 GB of workspace).
+        self.engine = engine if engine is not None else _native.Engine(device_id)
         self.engine.set_precision(precision)  # "split_f16" (default, fp32-class) or "f32" (exact fp32 matrix ops)
-        self.engine.load_state_dict(0, get_model(self.modelname, modelpath))
+        self.engine.load_state_dict(0, state_dict if state_dict is not None else get_model(self.modelname, modelpath))
         self.fill_slot = -1
         if self.fillmodel is not None:  # mask.py:136-139
-            self.engine.load_state_dict(1, get_model(self.fillmodel, fillmodel_path))
+            self.engine.load_state_dict(1, fill_state_dict if fill_state_dict is not None else get_model(self.fillmodel, fillmodel_path))
             self.fill_slot = 1
 
     def apply(self, image, out: Optional[np.ndarray] = None) -> np.ndarray:
@@ -161,10 +167,11 @@ class LMInferer:
 def apply(image, model=None, force_cpu=False, batch_size=20, volume_postprocessing=True, tqdm_disable=False):
     """Deprecated shim, mask.py:235-255.  `model` may be a state_dict."""
     warnings.warn("The function `apply` will be removed in a future version. Please use the LMInferer class!", DeprecationWarning)
-    inferer = LMInferer(force_cpu=force_cpu, batch_size=batch_size, volume_postprocessing=volume_postprocessing, tqdm_disable=tqdm_disable)
+    sd = None
     if model is not None:
         sd = model.state_dict() if hasattr(model, "state_dict") else model
-        inferer.engine.load_state_dict(0, sd)
+    inferer = LMInferer(force_cpu=force_cpu, batch_size=batch_size, volume_postprocessing=volume_postprocessing, tqdm_disable=tqdm_disable,
+                        state_dict=sd)
     return inferer.apply(image)
 
 

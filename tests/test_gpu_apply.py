@@ -308,9 +308,17 @@ def test_cli_npy_roundtrip(gpu_engine, tmp_path):
     assert main([str(ip), str(op), "--modelpath", str(wp), "--noprogress"]) == 0
     gpu_engine.load_state_dict(0, sd)
     assert np.array_equal(np.load(op), gpu_engine.apply(0, vol))
-    # --cpu (reference __main__.py:81-83) is accepted: there is no CPU path, the same result comes from the GPU
+    # --cpu (reference __main__.py:81-83): there is no CPU path -- an error by default, accepted (same result from the GPU) only
+    # with the explicit opt-in
     op2 = tmp_path / "out_cpu_flag.npy"
-    assert main([str(ip), str(op2), "--modelpath", str(wp), "--cpu", "--noprogress"]) == 0
+    with pytest.raises(RuntimeError, match="MI355X-only"):
+        main([str(ip), str(op2), "--modelpath", str(wp), "--cpu", "--noprogress"])
+    assert not op2.exists()
+    os.environ["LUNGMASK_AMD_ALLOW_CPU_FLAG"] = "1"
+    try:
+        assert main([str(ip), str(op2), "--modelpath", str(wp), "--cpu", "--noprogress"]) == 0
+    finally:
+        del os.environ["LUNGMASK_AMD_ALLOW_CPU_FLAG"]
     assert np.array_equal(np.load(op2), np.load(op))
 
 
