@@ -4,7 +4,11 @@
 
 Writes <out>_kernel_stats.csv (rocprofv3 --kernel-trace --stats), <out>_pmc.json (per-kernel FETCH_SIZE /
 WRITE_SIZE per launch, with the gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE counts 64 B per 128 B
-request on wide coalesced reads -> doubled; counters are in KiB)."""
+request on wide coalesced reads -> doubled; counters are in KiB).
+
+  ... --pin  additionally writes profiles/pmc_current.json = {file, commit, sha256 of the conv kernel's sources}: the ONE summary
+             bench.py's roofline.traffic may read, refused there as soon as one of those sources differs (run it on the tree the
+             PMC passes were measured on, before editing further)."""
 import collections
 import csv
 import glob
@@ -13,6 +17,7 @@ import os
 import sys
 
 src, out = sys.argv[1], sys.argv[2]
+PIN_SOURCES = ["lungmask_amd/csrc/nn_kernels_h3.hip", "lungmask_amd/csrc/nn_kernels.h", "lungmask_amd/csrc/nn_engine.hip", "lungmask_amd/csrc/lm_platform.h"]
 stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
@@ -45,3 +50,15 @@ json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate pa
            "workload": open(wl).read().strip() if os.path.exists(wl) else "",
            "kernels": pmc}, open(out + "_pmc.json", "w"), indent=1)
 print("wrote", out + "_kernel_stats.csv", out + "_pmc.json")
+
+if "--pin" in sys.argv[3:] and pmc:
+    import hashlib
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    commit = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=root, stdout=subprocess.PIPE, text=True).stdout.strip()
+    dirty = subprocess.run(["git", "status", "--porcelain", "--"] + PIN_SOURCES, cwd=root, stdout=subprocess.PIPE, text=True).stdout.strip()
+    pin = {"file": os.path.basename(out) + "_pmc.json", "commit": commit + ("+uncommitted kernel edits" if dirty else ""),
+           "sources_sha256": {rel: hashlib.sha256(open(os.path.join(root, rel), "rb").read()).hexdigest() for rel in PIN_SOURCES}}
+    json.dump(pin, open(os.path.join(root, "profiles", "pmc_current.json"), "w"), indent=1)
+    print("pinned", pin["file"], "at", pin["commit"])
