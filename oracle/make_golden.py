@@ -1,7 +1,10 @@
 """Generates tests/golden/*.npz from the REFERENCE implementation (dev
 container only; needs /root/reference and /opt/conda/bin/python3.9).
 
-  python oracle/make_golden.py
+  python oracle/make_golden.py [unet] [prepost] [testvol] [--out DIR]
+
+(--out DIR: write there instead of tests/golden -- tests/test_oracle.py::test_goldens_regenerate uses it to check that the
+recipe still reproduces the committed fixtures array for array, bit for bit, whenever /root/reference is mounted.)
 
 * unet_c{3,6}.npz  : reference `resunet.UNet` (mask.py:58-65 configuration)
                      on `oracle.unet_oracle.synthetic_state_dict(C)`;
@@ -186,7 +189,13 @@ def make_testvol():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["unet", "prepost", "testvol"]
+    argv = sys.argv[1:]
+    if "--out" in argv:
+        i = argv.index("--out")
+        GOLD = os.path.abspath(argv[i + 1])
+        os.makedirs(GOLD, exist_ok=True)
+        del argv[i : i + 2]
+    which = argv or ["unet", "prepost", "testvol"]
     if "testvol" in which:
         make_testvol()
     if "prepost" in which:

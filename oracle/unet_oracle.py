@@ -68,6 +68,27 @@ def forward_logits(sd, x: torch.Tensor, return_features: bool = False):
     return logits
 
 
+def calibrate_head(sd, x0: torch.Tensor, std: float):
+    """SURVEY.md Appendix D's head calibration: a copy of `sd` whose 1x1 head is rescaled so that, on the input x0, every class's
+    logit map has mean 0 and standard deviation `std` (`last.weight *= std/std_c(L)`, `last.bias = -mean_c(L)*std/std_c(L)`).
+    The recipe's std 8 gives logit ranges of a few tens up to +-100; tests sweep larger values."""
+    sd = OrderedDict(sd)
+    with torch.inference_mode():
+        sd["last.bias"] = torch.zeros_like(sd["last.bias"])
+        L = forward_logits(sd, x0)
+        s, m = L.std(dim=(0, 2, 3)), L.mean(dim=(0, 2, 3))
+        sd["last.weight"] = sd["last.weight"] * (std / s)[:, None, None, None]
+        sd["last.bias"] = -m * std / s
+    return sd
+
+
+def forward_f64(sd, x: torch.Tensor) -> torch.Tensor:
+    """The same graph evaluated in float64: what the reference's fp32 arithmetic itself is an approximation of.  Tests use
+    |forward - forward_f64| as the reference's own rounding noise for a given model (it grows with the logit range)."""
+    sd64 = {k: (v.double() if torch.is_floating_point(v) else v) for k, v in sd.items()}
+    return F.log_softmax(forward_logits(sd64, x.double()), dim=1)
+
+
 def forward(sd, x: torch.Tensor) -> torch.Tensor:
     """== UNet.forward: LogSoftmax(dim=1) of the logits (resunet.py:70)."""
     return F.log_softmax(forward_logits(sd, x), dim=1)

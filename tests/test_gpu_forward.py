@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import prepost_oracle as po
 from oracle import unet_oracle as uo
 
 pytestmark = pytest.mark.gpu
@@ -198,6 +199,46 @@ def test_forward_heavy_tailed_weights(gpu_engine):
     assert err < TOL * scale, (err, scale)
     margin = np.sort(ref, axis=1)[:, -1] - np.sort(ref, axis=1)[:, -2]
     assert not np.any((lab != ref.argmax(1)) & (margin > 2 * TOL * scale))
+
+
+@pytest.mark.parametrize("prec", ["split_f16", "f32"])
+def test_logit_range_sweep(gpu_engine, prec):
+    """the split-f16 error is relative, the 1e-3 bar absolute -- sweep the logit range with heads calibrated
+    per SURVEY Appendix D (every class's logit map at std 8 -- the recipe --, then 30 and 100) on the phantom's network input.
+    No tolerance scaling with the range for the recipe's own std 8: absolute 1e-3 against the torch-fp32 oracle.
+    Beyond that the REFERENCE's own fp32 arithmetic is the limit: |oracle_f32 - oracle_f64| measures 1.6e-4 at std 8, 6.2e-4 at
+    std 30 and 2.0e-3 at std 100 on this input (logits -316..+598), i.e. at std 100 the reference is further than the bar from
+    the exact value of its own graph and no implementation with another summation order can be within 1e-3 of it.  For those
+    models the engine is held to what is checkable: it must be as close to the float64 evaluation as the reference is (factor
+    2.5), and within 1e-3 + 2.5x the reference's own distance of the reference."""
+    base = uo.synthetic_state_dict(3)
+    ph = po.phantom(2, 512, 512)
+    xs, _ = po.preprocess(ph, [256, 256])
+    x = po.normalise(xs)
+    xt = torch.from_numpy(x[:, None])
+    gpu_engine.set_precision(prec)
+    try:
+        for std in (8.0, 30.0, 100.0):
+            sd = uo.calibrate_head(base, xt[:1], std)
+            gpu_engine.load_state_dict(0, sd)
+            lab, logp = gpu_engine.forward(0, x)
+            assert gpu_engine.model_precision(0) == prec  # the f16 range guard has no reason to trip
+            with torch.inference_mode():
+                ref = uo.forward(sd, xt).numpy()
+                ref64 = uo.forward_f64(sd, xt).numpy()
+                lg = uo.forward_logits(sd, xt)
+            noise = float(np.abs(ref - ref64).max())          # the reference's own rounding noise on this model
+            err = float(np.abs(logp - ref).max())             # engine vs reference (the north-star's quantity)
+            err64 = float(np.abs(logp - ref64).max())         # engine vs the exact evaluation
+            print(f"{prec} head std {std:g}: logits {float(lg.min()):.0f}..{float(lg.max()):.0f}  |engine-ref32| {err:.2e}  "
+                  f"|engine-ref64| {err64:.2e}  |ref32-ref64| {noise:.2e}")
+            if std == 8.0:
+                assert err < TOL, (std, err)
+            assert err < TOL + 2.5 * noise and err64 < max(TOL, 2.5 * noise), (std, err, err64, noise)
+            margin = np.sort(ref, axis=1)[:, -1] - np.sort(ref, axis=1)[:, -2]
+            assert not np.any((lab != ref.argmax(1)) & (margin > 2 * max(err, TOL)))
+    finally:
+        gpu_engine.set_precision("split_f16")
 
 
 def test_f16_range_guard_falls_back_to_exact_fp32(gpu_engine):

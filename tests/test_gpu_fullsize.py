@@ -5,11 +5,12 @@ For each configuration the whole hot path (`lm_apply_host`) is compared, voxel f
     oracle pre-processing -> [the engine's argmax labels] -> oracle post-processing -> oracle un-crop (-> oracle fusion)
 
 on the full 300-slice phantom, and the network forward is held to the near-tie rule against the torch-fp32
-oracle on a sample of slices spread over the volume (the oracle forward runs at ~7 slices/s on the host; the per-slice
-forward parity itself is test_gpu_forward.py's job).  The oracle's post-processing is `postprocessing_fast` (same statements
-with the per-region passes confined to bounding boxes; pinned to `postprocessing` and the reference goldens in the CPU
+oracle on ALL 300 slices for the headline configuration (R231), on every third slice for LTRCLobes and on a 23-slice sample
+for the second pass over the same two models in the fused configuration (the oracle forward runs at ~7 slices/s on the host).  The oracle's post-processing is
+`postprocessing_fast` (same statements with the per-region passes confined to bounding boxes; pinned to `postprocessing` and the reference goldens in the CPU
 suite): the statement-by-statement form needs minutes at this size.  Mismatch counts are printed.
 """
+import os
 import time
 
 import numpy as np
@@ -23,6 +24,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 N, H, W, BATCH = 300, 512, 512, 20
 SAMPLE = tuple(range(4, N, 13))  # 23 slices, every part of the lungs and both lung-free ends
+ORACLE_SLICES = {3: tuple(range(N)), 6: tuple(range(0, N, 3))}  # slices whose forward is checked against the oracle, per class count
 
 
 @pytest.fixture(scope="module")
@@ -50,15 +52,22 @@ def engine_labels(eng, slot, x):
     return lab
 
 
-def forward_near_tie_check(sd, x, lab):
-    idx = list(SAMPLE)
-    with torch.inference_mode():
-        ref = uo.forward(sd, torch.from_numpy(np.ascontiguousarray(x[idx])[:, None]))
-    srt = torch.sort(ref, dim=1, descending=True)[0]
-    margin = (srt[:, 0] - srt[:, 1]).numpy()
-    bad = lab[idx] != ref.argmax(1).numpy().astype(np.uint8)
-    assert not np.any(bad & (margin > 2 * TOL)), f"forward: {int(bad.sum())} label mismatches on the sampled slices, some away from near-ties"
-    return int(bad.sum()), int((margin < 2 * TOL).sum())
+def forward_near_tie_check(sd, x, lab, slices=SAMPLE):
+    """Engine labels vs the oracle's argmax on `slices`: equal wherever the oracle's top-2 margin exceeds 2 * TOL."""
+    idx = list(slices)
+    n_bad = n_tie = 0
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    for c0 in range(0, len(idx), 10):  # 10 slices at a time: the oracle keeps every activation of a batch (0.2 GB per slice)
+        part = idx[c0 : c0 + 10]
+        with torch.inference_mode():
+            ref = uo.forward(sd, torch.from_numpy(np.ascontiguousarray(x[part])[:, None]))
+        srt = torch.sort(ref, dim=1, descending=True)[0]
+        margin = (srt[:, 0] - srt[:, 1]).numpy()
+        bad = lab[part] != ref.argmax(1).numpy().astype(np.uint8)
+        assert not np.any(bad & (margin > 2 * TOL)), f"forward: label mismatches away from near-ties on slices {part}"
+        n_bad += int(bad.sum())
+        n_tie += int((margin < 2 * TOL).sum())
+    return n_bad, n_tie
 
 
 def uncrop(post, boxes, shape):
@@ -74,11 +83,13 @@ def test_full_size_single_model(gpu_engine, bench_volume, oracle_pre, n_classes)
     out = gpu_engine.apply(0, bench_volume, batch_size=BATCH)
     assert gpu_engine.model_precision(0) == "split_f16"
     lab = engine_labels(gpu_engine, 0, x)
-    n_bad, n_tie = forward_near_tie_check(sd, x, lab)
+    t = time.perf_counter()
+    n_bad, n_tie = forward_near_tie_check(sd, x, lab, ORACLE_SLICES[n_classes])
+    print(f"oracle forward of {len(ORACLE_SLICES[n_classes])} slices: {time.perf_counter() - t:.1f} s")
     t = time.perf_counter()
     expect = uncrop(po.postprocessing_fast(lab.copy()), boxes, bench_volume.shape[1:])
     n_diff = int((out != expect).sum())
-    print(f"C={n_classes}: forward mismatches on {len(SAMPLE)} sampled slices: {n_bad} (all among the {n_tie} near-tie pixels); "
+    print(f"C={n_classes}: forward mismatches on {len(ORACLE_SLICES[n_classes])} of {N} slices: {n_bad} (all among the {n_tie} near-tie pixels); "
           f"apply vs oracle(pre) + engine labels + oracle(post, un-crop): {n_diff} differing voxels of {out.size}; "
           f"label histogram {np.bincount(out.ravel()).tolist()}; oracle post {time.perf_counter() - t:.1f} s")
     assert n_diff == 0

@@ -114,3 +114,22 @@ def test_prepost_oracle_vs_reference_goldens(gpp):
         assert np.array_equal(po.bbox_3D(m), g[f"klc{i}_bbox"])
     for i in range(int(g["n_ac"])):
         assert np.array_equal(po.area_closing_binary(g[f"ac{i}_img"]), g[f"ac{i}_out"])
+
+
+@pytest.mark.skipif(not (os.path.isdir("/root/reference/lungmask") and os.path.exists("/opt/conda/bin/python3.9")),
+                    reason="needs the reference checkout and the conda interpreter of the dev container")
+def test_goldens_regenerate(tmp_path, golden_dir):
+    """The committed fixtures ARE what `oracle/make_golden.py` produces from the reference today: regenerating into a scratch
+    directory reproduces every array bit for bit (the .npz containers themselves carry zip timestamps).  Guards against the
+    recipe and the fixtures drifting apart (e.g. a workload generator edited after the fixtures were written)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, os.path.join(root, "oracle", "make_golden.py"), "--out", str(tmp_path)], check=True,
+                   stdout=subprocess.DEVNULL, env=dict(os.environ, OMP_NUM_THREADS="8"))
+    for name in ("unet_c3.npz", "unet_c6.npz", "prepost.npz", "testvol.npz"):
+        a, b = np.load(os.path.join(golden_dir, name), allow_pickle=True), np.load(tmp_path / name, allow_pickle=True)
+        assert sorted(a.files) == sorted(b.files), name
+        for k in a.files:
+            assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), (name, k)
