@@ -57,6 +57,7 @@ int lm_engine_create(lm_engine** out, int device_id) {
 
 void lm_engine_destroy(lm_engine* e) {
     if (!e) return;
+    e->helper.stop();
     (void)lm_dist_destroy(e);
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
@@ -328,44 +329,49 @@ int lm_apply_host(lm_engine* e, int slot, int fill_slot, const void* vol_host, i
     LM_TRY(e->app.vol.reserve(nvox * esz));
     LM_TRY(e->app.out.reserve(nvox));
     // mask.py:178-186 moves every batch to the device and back on its own; here the boundary is crossed once per volume, in two
-    // pieces.  The head (two batches) goes in on the main stream, and while it is pre-processed and run through the network a
-    // helper thread (a) copies the tail in on a second stream and (b) touches every page of the caller's output array, so that
-    // the copy back at the end does not take the page faults of a freshly allocated buffer.
+    // pieces.  The head (two batches) goes in on the main stream, and while it is pre-processed and run through the network the
+    // engine's helper thread (persistent: started on the first call, parked between calls) (a) copies the tail in on a second
+    // stream and (b) faults in every page of the caller's output array WITHOUT changing it (each page's first byte is read and
+    // written back), so that the copy back at the end does not take the page faults of a freshly allocated buffer.  The
+    // caller's array is only ever overwritten by the final copy of a successful call; on any error it is left as it was.
     if (batch_size <= 0) batch_size = 20;
     const int head = (e->n_streams > 1 ? 2 : 1) * batch_size;
-    const bool split = n > head;
+    bool split = n > head;
     if (split && !e->copy_stream) {
         if (hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->tail_ready, hipEventDisableTiming) != hipSuccess) {
             set_error("lm_apply_host: creating the copy stream failed");
             return LM_ERR_DEVICE;
         }
     }
+    const bool threaded = e->helper.start();  // false: no thread could be created -- one copy on the main stream, no page touching
+    if (!threaded) split = false;
     static const bool timing = [] { const char* v = getenv("LM_HOST_TIMING"); return v && v[0] == '1'; }();  // stderr breakdown of this call
     const auto t_start = std::chrono::steady_clock::now();
     auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     double t_tail = 0, t_touch = 0;
     e->tail_enqueued.store(0, std::memory_order_release);
-    std::thread helper([&] {
-        hipError_t terr = hipSuccess;
-        if (split) {
-            terr = hipSetDevice(e->device);
-            // (a pageable source makes this call return only when the data has been staged: that is why it lives on this thread)
-            if (terr == hipSuccess)
-                terr = hipMemcpyAsync(reinterpret_cast<char*>(e->app.vol.p) + (size_t)head * slice * esz, reinterpret_cast<const char*>(vol_host) + (size_t)head * slice * esz,
-                                      (size_t)(n - head) * slice * esz, hipMemcpyHostToDevice, e->copy_stream);
-            if (terr == hipSuccess) terr = hipEventRecord(e->tail_ready, e->copy_stream);
-        }
-        e->tail_enqueued.store(terr == hipSuccess ? 1 : -1, std::memory_order_release);
-        t_tail = ms_since(t_start);
-        // (Pinning the caller's array here with hipHostRegister makes the copy back 0.4 ms faster -- tools/host_pin_probe.py -- but an
-        // array from the malloc heap shares its first and last page with other objects and with the runtime's own cache of pinned
-        // user ranges; one whole-suite run aborted inside the next model load after such a registration, so the pages are touched.)
-        volatile uint8_t* o = out_host;
-        for (size_t i = 0; i < nvox; i += 4096) o[i] = 0;
-        if (nvox) o[nvox - 1] = 0;
-        t_touch = ms_since(t_start);
-    });
-    hipError_t err = hipMemcpyAsync(e->app.vol.p, vol_host, (size_t)std::min(n, head) * slice * esz, hipMemcpyHostToDevice, e->stream);
+    if (threaded)
+        e->helper.run([&, split] {
+            hipError_t terr = hipSuccess;
+            if (split) {
+                terr = hipSetDevice(e->device);
+                // (a pageable source makes this call return only when the data has been staged: that is why it lives on this thread)
+                if (terr == hipSuccess)
+                    terr = hipMemcpyAsync(reinterpret_cast<char*>(e->app.vol.p) + (size_t)head * slice * esz, reinterpret_cast<const char*>(vol_host) + (size_t)head * slice * esz,
+                                          (size_t)(n - head) * slice * esz, hipMemcpyHostToDevice, e->copy_stream);
+                if (terr == hipSuccess) terr = hipEventRecord(e->tail_ready, e->copy_stream);
+            }
+            e->tail_enqueued.store(terr == hipSuccess ? 1 : -1, std::memory_order_release);
+            t_tail = ms_since(t_start);
+            // (Pinning the caller's array here with hipHostRegister makes the copy back 0.4 ms faster -- tools/host_pin_probe.py -- but an
+            // array from the malloc heap shares its first and last page with other objects and with the runtime's own cache of pinned
+            // user ranges; one whole-suite run aborted inside the next model load after such a registration, so the pages are touched.)
+            volatile uint8_t* o = out_host;
+            for (size_t i = 0; i < nvox; i += 4096) o[i] = o[i];
+            if (nvox) o[nvox - 1] = o[nvox - 1];
+            t_touch = ms_since(t_start);
+        });
+    hipError_t err = hipMemcpyAsync(e->app.vol.p, vol_host, (size_t)(split ? head : n) * slice * esz, hipMemcpyHostToDevice, e->stream);
     const double t_head = ms_since(t_start);
     int rc = LM_OK;
     if (err != hipSuccess) {
@@ -377,14 +383,17 @@ int lm_apply_host(lm_engine* e, int slot, int fill_slot, const void* vol_host, i
         e->head_slices = 0;
     }
     const double t_apply = ms_since(t_start);
-    helper.join();
+    if (threaded) e->helper.wait();
     const double t_join = ms_since(t_start);
-    hipError_t back = hipSuccess;
-    if (rc == LM_OK) {
-        back = hipMemcpyAsync(out_host, e->app.out.p, nvox, hipMemcpyDeviceToHost, e->stream);
-        if (back == hipSuccess) back = hipStreamSynchronize(e->stream);
+    if (rc != LM_OK) {
+        // the tail copy may still be reading the caller's volume / writing the staging buffer: nothing of this call may be in
+        // flight when it returns
+        if (split && e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
+        (void)hipStreamSynchronize(e->stream);
+        return rc;
     }
-    if (rc != LM_OK) return rc;
+    hipError_t back = hipMemcpyAsync(out_host, e->app.out.p, nvox, hipMemcpyDeviceToHost, e->stream);
+    if (back == hipSuccess) back = hipStreamSynchronize(e->stream);
     if (back != hipSuccess) {
         set_error("lm_apply_host: device-to-host copy failed: %s", hipGetErrorString(back));
         return LM_ERR_DEVICE;

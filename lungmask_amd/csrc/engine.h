@@ -1,10 +1,14 @@
 // Host-side engine state behind the C ABI (include/lungmask_hip.h).
 #pragma once
 #include <atomic>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/lungmask_hip.h"
@@ -150,6 +154,65 @@ struct PostInfo {
     double host_replay_ms = 0;
 };
 
+// One persistent helper thread per engine (lm_apply_host's second copy lane): started on first use, parked on a condition
+// variable between calls, joined by lm_engine_destroy.  run() hands it ONE job; wait() blocks until that job has returned.
+// start() reports failure instead of throwing (a std::thread that cannot be created must not unwind through the C ABI): the
+// caller then takes its single-threaded path.
+class HostHelper {
+public:
+    bool start() noexcept {
+        if (started_) return true;
+        try {
+            th_ = std::thread([this] { loop(); });
+        } catch (...) {
+            return false;
+        }
+        started_ = true;
+        return true;
+    }
+    void run(std::function<void()> job) {
+        std::lock_guard<std::mutex> g(m_);
+        job_ = std::move(job);
+        busy_ = true;
+        cv_.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [this] { return !busy_; });
+    }
+    void stop() {
+        if (!started_) return;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            quit_ = true;
+            cv_.notify_all();
+        }
+        th_.join();
+        started_ = false;
+    }
+
+private:
+    void loop() {
+        std::unique_lock<std::mutex> g(m_);
+        for (;;) {
+            cv_.wait(g, [this] { return quit_ || (busy_ && job_); });
+            if (quit_) return;
+            std::function<void()> job = std::move(job_);
+            job_ = nullptr;
+            g.unlock();
+            job();
+            g.lock();
+            busy_ = false;
+            cv_.notify_all();
+        }
+    }
+    std::thread th_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::function<void()> job_;
+    bool started_ = false, busy_ = false, quit_ = false;
+};
+
 }  // namespace lm
 
 struct lm_engine {
@@ -180,6 +243,7 @@ struct lm_engine {
     // set by the copying thread once tail_ready has been recorded (1) or the copy failed (-1): the hot path must not enqueue
     // its wait on an event that has not been recorded yet (that would be a no-op)
     std::atomic<int> tail_enqueued{0};
+    lm::HostHelper helper;
     unsigned* range_flag = nullptr;       // device word of the f16 range guard (ConvParamsH3::range_flag)
     unsigned* range_flag_host = nullptr;  // pinned copy
     // lm_dist_* (dist_rccl.hip): RCCL communicator of this engine's rank; world 0 = none, world 1 = no library involved

@@ -267,11 +267,24 @@ __device__ __forceinline__ void lm_split4(float v0, float v1, float v2, float v3
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     typedef float f4 __attribute__((ext_vector_type(4)));
     const f4 v = {v0, v1, v2, v3};
-    const h4 h = __builtin_convertvector(v, h4);
+    const h4 h = __builtin_convertvector(v, h4);  // 2 x v_cvt_pk_f16_f32
+    __builtin_memcpy(hi, &h, 8);
+#ifndef LM_SPLIT_NO_MIX
+    // lo = f16(v - f32(hi)) in ONE mixed-precision fma per value (f32 v * 1.0 - f16 hi, rounded once to f16: v - hi is exact in
+    // f32, so this is bit for bit the convert / subtract / convert sequence, f16 denormals included -- tools/ubench/split_mix.hip
+    // checks it on the hardware): 6 VALU per 4 values instead of 12.
+    unsigned l01, l23;
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l01) : "v"(v0), "v"(hi->x));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l01) : "v"(v1), "v"(hi->x));
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l23) : "v"(v2), "v"(hi->y));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l23) : "v"(v3), "v"(hi->y));
+    lo->x = l01;
+    lo->y = l23;
+#else
     const f4 r = v - __builtin_convertvector(h, f4);
     const h4 l = __builtin_convertvector(r, h4);
-    __builtin_memcpy(hi, &h, 8);
     __builtin_memcpy(lo, &l, 8);
+#endif
 #endif
     lo->x = lm_round_lo_pair(lo->x);
     lo->y = lm_round_lo_pair(lo->y);

@@ -413,7 +413,10 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
     const lm_rsrc rsrcW = lm_make_rsrc(p.w, (size_t)TAPS * p.Cout * p.Cin * 4);
     const int tiles_x = p.W / TWW;
     const int nchunks = p.Cin / KC;  // even (checked by the launcher)
-    const bool bn = p.bn_s != nullptr;
+    // Conv -> ReLU -> BatchNorm for every 3x3 conv of the network, bias only for the decoder's 1x1 convs (resunet.py:93-105,
+    // :131-133): a property of the instantiation, not a run-time select per value (the launcher sends anything else to the
+    // simple kernel)
+    constexpr bool bn = TAPS == 9;
 
     // Work-item order.  `it` runs over a (padded) index space; workgroup g takes it = g, g + grid, ... and lives on XCD
     // g % 8 (workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MB L2).
@@ -620,6 +623,15 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                     const int bmask = (yl == 0 ? 1 : 0) | (yl == p.H - 1 ? 2 : 0) | (x0 + li == 0 ? 4 : 0) | (x0 + li == p.W - 1 ? 8 : 0);
                     const bool border = p.border_corr != nullptr && __any(bmask != 0);  // wave-uniform
                     float vv[8][4];
+                    // deferred-shift input: the taps outside the image saw 0, not -T (ConvParamsH3::border_corr).  All eight
+                    // channel groups' corrections are fetched in ONE round trip up front (the fragment registers are free
+                    // here); fetched one group at a time inside the loop they were eight serial cache latencies per row for
+                    // every wave of every item that touches the image border -- all items from the 64 x 64 level down.
+                    float4 cb[8];
+                    if (border) {
+#pragma unroll
+                        for (int mg = 0; mg < 8; ++mg) cb[mg] = *reinterpret_cast<const float4*>(p.border_corr + (size_t)bmask * p.Cout + n0 + H3P_EPI_CL(mg));
+                    }
                     lm_h16x8 ec[2][3];  // the constants of channel group mg + 1 are fetched under the arithmetic of group mg
                     H3P_EPI_READS(ec[0], H3P_EPI_CL(0));
 #pragma unroll
@@ -635,8 +647,8 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                         const float4 bias = as_float4(ec[mg & 1][0]), s = as_float4(ec[mg & 1][1]), sh = as_float4(ec[mg & 1][2]);
                         float bb[4] = {bias.x, bias.y, bias.z, bias.w};
                         const float ss[4] = {s.x, s.y, s.z, s.w}, tt[4] = {sh.x, sh.y, sh.z, sh.w};
-                        if (border) {  // deferred-shift input: the taps outside the image saw 0, not -T (ConvParamsH3::border_corr)
-                            const float4 c = *reinterpret_cast<const float4*>(p.border_corr + (size_t)bmask * p.Cout + n0 + cl);
+                        if (border) {
+                            const float4 c = cb[mg];
                             bb[0] -= c.x;
                             bb[1] -= c.y;
                             bb[2] -= c.z;
@@ -692,6 +704,11 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                 const int xl = G16 ? wcol : x0 + li;
                 const int bmask = (yl == 0 ? 1 : 0) | (yl == p.H - 1 ? 2 : 0) | (xl == 0 ? 4 : 0) | (xl == p.W - 1 ? 8 : 0);
                 const bool border = TAPS == 9 && p.border_corr != nullptr && __any(bmask != 0);  // wave-uniform
+                float4 cb[8];  // border corrections of all eight channel groups, one round trip (see the fused-head form)
+                if (border) {
+#pragma unroll
+                    for (int mg = 0; mg < 8; ++mg) cb[mg] = *reinterpret_cast<const float4*>(p.border_corr + (size_t)bmask * p.Cout + n0 + H3P_EPI_CL(mg));
+                }
                 lm_h16x8 ec[2][3];  // the constants of channel group mg + 1 are fetched under the arithmetic of group mg
                 H3P_EPI_READS(ec[0], H3P_EPI_CL(0));
 #pragma unroll
@@ -708,7 +725,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                     float bb[4] = {bias.x, bias.y, bias.z, bias.w};
                     const float ss[4] = {s.x, s.y, s.z, s.w}, tt[4] = {sh.x, sh.y, sh.z, sh.w};
                     if (border) {
-                        const float4 c = *reinterpret_cast<const float4*>(p.border_corr + (size_t)bmask * p.Cout + n0 + cl);
+                        const float4 c = cb[mg];
                         bb[0] -= c.x;
                         bb[1] -= c.y;
                         bb[2] -= c.z;
@@ -797,7 +814,7 @@ static bool h3_persistent_ok(const ConvParamsH3& p, int taps) {
     static const bool wide_ok = [] { const char* e = getenv("LM_H3_FALLBACK"); return !(e && e[0] == '1'); }();
     const size_t slice_bytes = (size_t)p.H * p.W * p.in_cstride * 4;
     return wide_ok && (p.W % 32 == 0 || p.W == 16) && (p.Cin / KC) % (taps == 1 ? 4 : 2) == 0 && 2 * slice_bytes < 0x7fffffffull &&
-           (size_t)taps * p.Cout * p.Cin * 4 < 0x7fffffffull;
+           (size_t)taps * p.Cout * p.Cin * 4 < 0x7fffffffull && (p.bn_s != nullptr) == (taps == 9);
 }
 
 template <int TAPS>

@@ -210,7 +210,11 @@ def test_logit_range_sweep(gpu_engine, prec):
     std 30 and 2.0e-3 at std 100 on this input (logits -316..+598), i.e. at std 100 the reference is further than the bar from
     the exact value of its own graph and no implementation with another summation order can be within 1e-3 of it.  For those
     models the engine is held to what is checkable: it must be as close to the float64 evaluation as the reference is (factor
-    2.5), and within 1e-3 + 2.5x the reference's own distance of the reference."""
+    2.5), and within 1e-3 + 2.5x the reference's own distance of the reference.
+    The exact-fp32 kernels (the fall-back of the f16 range guard) are swept too: their v_mfma_f32_32x32x2_f32 accumulation is one
+    fp32 rounding per TWO products along K <= 9216, against one per SIXTEEN on the split path (the 16 exact f16 products of an
+    instruction are summed before the accumulator is touched) -- they are the LESS accurate of the two (measured 6.4e-4 at std 8,
+    4x the reference's own noise) and get a factor of 5."""
     base = uo.synthetic_state_dict(3)
     ph = po.phantom(2, 512, 512)
     xs, _ = po.preprocess(ph, [256, 256])
@@ -234,7 +238,8 @@ def test_logit_range_sweep(gpu_engine, prec):
                   f"|engine-ref64| {err64:.2e}  |ref32-ref64| {noise:.2e}")
             if std == 8.0:
                 assert err < TOL, (std, err)
-            assert err < TOL + 2.5 * noise and err64 < max(TOL, 2.5 * noise), (std, err, err64, noise)
+            k = 2.5 if prec == "split_f16" else 5.0
+            assert err < TOL + k * noise and err64 < max(TOL, k * noise), (std, err, err64, noise)
             margin = np.sort(ref, axis=1)[:, -1] - np.sort(ref, axis=1)[:, -2]
             assert not np.any((lab != ref.argmax(1)) & (margin > 2 * max(err, TOL)))
     finally:
