@@ -62,6 +62,16 @@ __device__ __forceinline__ void lm_wave_lds_fence() {
 #endif
 }
 
+// The value of lane ^ 1 (the x + 1 partner of the 2x2 average pool): a DPP quad permutation on the GPU -- a modifier of the
+// consuming VALU instruction or one v_mov_dpp -- instead of __shfl_xor's ds_bpermute_b32 through the LDS crossbar.
+__device__ __forceinline__ float lm_lane_xor1(float v) {
+#ifdef LM_EMU_BUILD
+    return __shfl_xor(v, 1);
+#else
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
+#endif
+}
+
 // A value the program knows to be wave-uniform, made provably so for the compiler (SGPR instead of a
 // per-lane VGPR + waterfall loop).
 __device__ __forceinline__ int lm_uniform(int x) {

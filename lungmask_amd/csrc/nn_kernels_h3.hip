@@ -759,6 +759,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                         }
                     }
                 }
+                LM_TRACE_SUB(5);
                 // the wave's own 32 pixels x 256 B are now in LDS (same-wave LDS ops are ordered): stream them out.
                 // G32: 32 consecutive pixels of one image row; G16 (W == 16): two consecutive 16-pixel rows = 32 consecutive pixels.
                 lm_wave_lds_fence();
@@ -773,17 +774,37 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                     }
                 }
                 lm_wave_lds_fence();  // the staging rows are rewritten by the next row
+                LM_TRACE_SUB(6);
             }
             if (!G16 && p.pool != nullptr) {  // avg_pool2d(2): rows yb, yb+1 summed above; x+1 is lane^1
-                char* prow = p.pool + ((((size_t)bs * Hp + (yb >> 1)) * Wp + ((x0 + li) >> 1)) * p.pool_cstride + p.pool_coff) * 4;
+                // The wave's pooled output is ONE row of 16 pixels x 64 channels = 16 x 256 B.  It goes through the staging rows
+                // like the full-resolution output (the even lanes' 8-byte pieces straight to memory were 16 scattered stores
+                // at a 256-byte stride per wave -- ~4.7 k cycles per item in the in-kernel timeline, four layers of the network).
 #pragma unroll
                 for (int mg = 0; mg < 8; ++mg) {
-                    const int cg = n0 + 32 * (mg >> 2) + 8 * (mg & 3) + 4 * kb;
+                    const int cl = H3P_EPI_CL(mg);
                     float q[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) q[k] = 0.25f * (pl[mg][k] + __shfl_xor(pl[mg][k], 1));
-                    if ((li & 1) == 0 && yb + 1 < p.H) split_store4(prow + (size_t)(cg >> 3) * 32, (cg & 7) * 2, q[0], q[1], q[2], q[3]);
+                    for (int k = 0; k < 4; ++k) q[k] = 0.25f * (pl[mg][k] + lm_lane_xor1(pl[mg][k]));
+                    uint2 ph, plo;
+                    lm_split4(q[0], q[1], q[2], q[3], &ph, &plo);
+                    if ((li & 1) == 0) {
+                        char* d = stage + (li >> 1) * PSTR + (cl >> 3) * 32 + (cl & 7) * 2;
+                        *reinterpret_cast<uint2_a*>(d) = ph;
+                        *reinterpret_cast<uint2_a*>(d + 16) = plo;
+                    }
                 }
+                lm_wave_lds_fence();
+                if (bs < p.B && yb + 1 < p.H) {
+                    char* prow = p.pool + ((((size_t)bs * Hp + (yb >> 1)) * Wp + (x0 >> 1)) * p.pool_cstride + p.pool_coff + n0) * 4;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int q = i * 64 + lane, px = q >> 4, part = q & 15;
+                        const uint4 val = *reinterpret_cast<const uint4_a*>(stage + px * PSTR + part * 16);
+                        *reinterpret_cast<uint4_a*>(prow + (size_t)px * p.pool_cstride * 4 + part * 16) = val;
+                    }
+                }
+                lm_wave_lds_fence();
             }
             }  // stored-output epilogue
             if (p.range_flag != nullptr && lm_pk_out_of_f16_guard(gmax)) atomicOr(p.range_flag, 1u);

@@ -71,10 +71,14 @@ int main(int argc, char** argv) {
         fill_f32<<<4, 256>>>(bias, s.Cout, -0.1f, 0.1f, 3u);
         fill_f32<<<4, 256>>>(bs, s.Cout, 0.75f, 1.25f, 4u);
         fill_f32<<<4, 256>>>(bt, s.Cout, -0.1f, 0.1f, 5u);
+        float* corr = nullptr;  // the product runs every 3x3 conv with a border-correction table (deferred BatchNorm shift)
+        CK(hipMalloc(&corr, 16 * s.Cout * 4));
+        fill_f32<<<16, 256>>>(corr, 16 * (size_t)s.Cout, -0.05f, 0.05f, 6u);
         lm::ConvParamsH3 p{};
         p.in = in; p.in_cstride = s.Cin; p.in_coff = 0; p.w = w; p.acc_scale = 1.f; p.bias = bias; p.bn_s = bs; p.bn_t = bt;
         p.out = out; p.out_cstride = s.Cout; p.out_coff = 0; p.pool = pool; p.pool_cstride = s.Cout; p.pool_coff = 0; p.zeros = zeros;
         p.B = B; p.H = s.H; p.W = s.H; p.Cin = s.Cin; p.Cout = s.Cout;
+        if (!getenv("LM_LAB_NO_BORDER")) p.border_corr = corr;
         for (int i = 0; i < 2; ++i) CK(lm::launch_conv3x3_h3(p, 0));
         CK(hipDeviceSynchronize());
         if (getenv("LM_LAB_VERIFY")) {  // the persistent kernel against the simple 4-wave kernel: outputs must agree bit for bit
@@ -126,7 +130,7 @@ int main(int argc, char** argv) {
             }
             printf("%-22s %9.4f %9.1f (timeline build)\n", fn, ms, 2.0 * npx * s.Cout * s.Cin * 9 / ms / 1e9);
             (void)hipFree(in); (void)hipFree(out); (void)hipFree(w); if (pool) (void)hipFree(pool);
-            (void)hipFree(bias); (void)hipFree(bs); (void)hipFree(bt);
+            (void)hipFree(bias); (void)hipFree(bs); (void)hipFree(bt); (void)hipFree(corr);
             continue;
         }
 #endif
@@ -148,7 +152,7 @@ int main(int argc, char** argv) {
         tot_ms += ms;
         tot_flop += flop;
         (void)hipFree(in); (void)hipFree(out); (void)hipFree(w); if (pool) (void)hipFree(pool);
-        (void)hipFree(bias); (void)hipFree(bs); (void)hipFree(bt);
+        (void)hipFree(bias); (void)hipFree(bs); (void)hipFree(bt); (void)hipFree(corr);
     }
     // weights: the 64->64 and Cin->Cin layers appear twice in the network (13 shapes, 17 launches)
     printf("sum over the 13 shapes: %.3f ms, %.1f TFLOP/s\n", tot_ms, tot_flop / tot_ms / 1e9);
