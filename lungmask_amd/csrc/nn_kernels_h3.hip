@@ -354,8 +354,8 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
     // is the conflict-free choice (enumerated over lane groups x dx x hi/lo; with >> 2 SQ_LDS_BANK_CONFLICT was 23 % of
     // the LDS cycles, now 1 %).  The 1x1 form has no halo (rows a whole number of bank sets apart): >> 2 for both widths.
     constexpr int ASWZ = (G16 && TAPS == 9) ? 1 : 2;
-    constexpr int PSTR = 272;                   // staged pixel stride of the epilogue: 256 B of split data + 16 B pad
-    constexpr int STAGE_BYTES = NW * 32 * PSTR;  // one 32-pixel row per wave
+    constexpr int HSTR = 144;                    // staged pixel stride of an epilogue pass: 128 B (32 channels) of split data + 16 B pad
+    constexpr int STAGE_BYTES = NW * 64 * HSTR;  // both rows of every wave, half of the item's channels
     // The epilogue staging area reuses the DMA buffer of the last chunk when it fits (3x3: 75 KiB), else it is extra.
     // A pipeline stage of the 1x1 form holds TWO chunk images (32 channels per barrier: with 16 the kernel is bound by the
     // barrier + DMA round trip, not by anything it computes); the 3x3 form holds one.
@@ -602,9 +602,9 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
         // ---- epilogue of this item (the first chunk of the next item is already resident in buffer 0)
         {
             // All waves are done with the buffer of the last chunk (buffer 1): it becomes the staging area that turns the
-            // accumulator layout (lane = pixel, 8 bytes per 4 couts: 64 scattered lines per store) into full
-            // 256-byte pixel rows written 16 bytes per lane (the scattered form cost ~10 us per tile in the TA).
-            char* stage = (STAGE_EXTRA ? lds + 2 * SUB * SM::BUF_BYTES : buf1) + wave * (32 * PSTR);
+            // accumulator layout (lane = pixel, 8 bytes per 4 couts: 64 scattered lines per store) into
+            // 128-byte pixel lines written 16 bytes per lane (the scattered form cost ~10 us per tile in the TA).
+            char* const hstage = (STAGE_EXTRA ? lds + 2 * SUB * SM::BUF_BYTES : buf1) + wave * (64 * HSTR);
             unsigned gmax = 0u;  // running max of the |hi| halves this lane writes (f16 range guard, lm_pk_absmax_u16)
             const int bs = b + wsl;                      // slice this wave writes
             const int yb = y0 + (G16 ? 4 * (wave & 3) : 2 * wave);  // first image row of the wave's N-tile 0
@@ -695,116 +695,143 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                     if (tile_ok && kb == 1) p.head_labels[((size_t)bs * p.H + yl) * p.W + x0 + li] = (uint8_t)arg;
                 }
             } else {
-            float pl[8][4];  // G32: row yb + row yb+1 (for the pool)
+            // Stored output, one pass per M-tile (32 of the item's 64 channels): per 4-channel group the epilogue constants are
+            // read ONCE and both rows of the wave go through the arithmetic as two independent dependency chains (the chain
+            // bias -> ReLU -> scale -> split -> stage is ~8 dependent VALU results long and the hand-placed waits keep the
+            // compiler from overlapping consecutive groups: row after row it ran at ~370 cycles per group); the pooled value
+            // of a group is complete as soon as both rows are, so no per-row accumulator array lives across the passes.
+            // Staging: 64 pixels x (128 B + 16 B pad) per wave and pass.
+            int yl2[2], bmask2[2];
+            bool ok2[2], border2[2];
+            char* obase[2];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 // image row of this lane's pixel in N-tile nt, and whether the wave's 32 pixels of this N-tile exist
-                const int yl = G16 ? yb + 2 * nt + (li >> 4) : yb + nt;
-                const bool tile_ok = bs < p.B && (G16 ? yb + 2 * nt + 1 < p.H : yb + nt < p.H);
+                yl2[nt] = G16 ? yb + 2 * nt + (li >> 4) : yb + nt;
+                ok2[nt] = bs < p.B && (G16 ? yb + 2 * nt + 1 < p.H : yb + nt < p.H);
                 const int xl = G16 ? wcol : x0 + li;
-                const int bmask = (yl == 0 ? 1 : 0) | (yl == p.H - 1 ? 2 : 0) | (xl == 0 ? 4 : 0) | (xl == p.W - 1 ? 8 : 0);
-                const bool border = TAPS == 9 && p.border_corr != nullptr && __any(bmask != 0);  // wave-uniform
-                float4 cb[8];  // border corrections of all eight channel groups, one round trip (see the fused-head form)
-                if (border) {
+                bmask2[nt] = (yl2[nt] == 0 ? 1 : 0) | (yl2[nt] == p.H - 1 ? 2 : 0) | (xl == 0 ? 4 : 0) | (xl == p.W - 1 ? 8 : 0);
+                border2[nt] = TAPS == 9 && p.border_corr != nullptr && __any(bmask2[nt] != 0);  // wave-uniform
+                // G32: 32 consecutive pixels of one image row; G16 (W == 16): two consecutive 16-pixel rows = 32 consecutive pixels
+                const int y_first = G16 ? yb + 2 * nt : yb + nt;
+                obase[nt] = p.out + ((((size_t)bs * p.H + y_first) * p.W + x0) * p.out_cstride + p.out_coff + n0) * 4;
+            }
 #pragma unroll
-                    for (int mg = 0; mg < 8; ++mg) cb[mg] = *reinterpret_cast<const float4*>(p.border_corr + (size_t)bmask * p.Cout + n0 + H3P_EPI_CL(mg));
-                }
-                lm_h16x8 ec[2][3];  // the constants of channel group mg + 1 are fetched under the arithmetic of group mg
-                H3P_EPI_READS(ec[0], H3P_EPI_CL(0));
+            for (int mt = 0; mt < 2; ++mt) {
+                // border corrections (deferred-shift input: the taps outside the image saw 0, not -T, ConvParamsH3::border_corr):
+                // the loads of channel group g4 + 1 are in flight under the arithmetic of group g4 (fetched where they were
+                // used they were a serial cache latency per group for every wave of every item that touches the image border
+                // -- all items from the 64 x 64 level down)
+                float4 cb[2][2];
+                auto load_cb = [&](int g4) __attribute__((always_inline)) {
 #pragma unroll
-                for (int mg = 0; mg < 8; ++mg) {
-                    const int mt = mg >> 2, g4 = mg & 3;
+                    for (int nt = 0; nt < 2; ++nt)
+                        if (border2[nt])
+                            cb[g4 & 1][nt] = *reinterpret_cast<const float4*>(p.border_corr + (size_t)bmask2[nt] * p.Cout + n0 + H3P_EPI_CL(4 * mt + g4));
+                };
+                load_cb(0);
+                float qs[4][4];     // pooled groups of this pass (32-wide geometry)
+                lm_h16x8 ec[2][3];  // the constants of channel group g4 + 1 are fetched under the arithmetic of group g4
+                H3P_EPI_READS(ec[0], H3P_EPI_CL(4 * mt));
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int mg = 4 * mt + g4;
                     const int cl = H3P_EPI_CL(mg);  // first of 4 consecutive local output channels
-                    if (mg + 1 < 8) {
-                        H3P_EPI_READS(ec[(mg + 1) & 1], H3P_EPI_CL(mg + 1));
-                        LM_LDS_WAIT3(3, ec[mg & 1][0], ec[mg & 1][1], ec[mg & 1][2]);
+                    if (g4 + 1 < 4) {
+                        H3P_EPI_READS(ec[(g4 + 1) & 1], H3P_EPI_CL(mg + 1));
+                        LM_LDS_WAIT3(3, ec[g4 & 1][0], ec[g4 & 1][1], ec[g4 & 1][2]);
                     } else {
-                        LM_LDS_WAIT3(0, ec[mg & 1][0], ec[mg & 1][1], ec[mg & 1][2]);
+                        LM_LDS_WAIT3(0, ec[g4 & 1][0], ec[g4 & 1][1], ec[g4 & 1][2]);
                     }
-                    const float4 bias = as_float4(ec[mg & 1][0]), s = as_float4(ec[mg & 1][1]), sh = as_float4(ec[mg & 1][2]);
-                    float bb[4] = {bias.x, bias.y, bias.z, bias.w};
+                    const float4 bias = as_float4(ec[g4 & 1][0]), s = as_float4(ec[g4 & 1][1]), sh = as_float4(ec[g4 & 1][2]);
                     const float ss[4] = {s.x, s.y, s.z, s.w}, tt[4] = {sh.x, sh.y, sh.z, sh.w};
-                    if (border) {
-                        const float4 c = cb[mg];
-                        bb[0] -= c.x;
-                        bb[1] -= c.y;
-                        bb[2] -= c.z;
-                        bb[3] -= c.w;
-                    }
-                    float v[4];
+                    if (g4 + 1 < 4) load_cb(g4 + 1);
+                    float v[2][4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        float t = fmaf(accm[mt][nt][4 * g4 + k], p.acc_scale, bb[k]);
-                        if (bn) t = fmaf(fmaxf(t, 0.f), ss[k], tt[k]);
-                        v[k] = t;
-                        if (!G16) pl[mg][k] = nt == 0 ? t : pl[mg][k] + t;
-                    }
-                    uint2 ph, plo;
-                    lm_split4(v[0], v[1], v[2], v[3], &ph, &plo);
-                    gmax = lm_pk_absmax_u16(lm_pk_absmax_u16(gmax, ph.x), ph.y);
-                    char* d = stage + li * PSTR + (cl >> 3) * 32 + (cl & 7) * 2;
-                    *reinterpret_cast<uint2_a*>(d) = ph;
-                    *reinterpret_cast<uint2_a*>(d + 16) = plo;
-                    if (G16 && p.pool != nullptr) {  // both pool partners are in this N-tile: lane^16 (y+1) and lane^1 (x+1)
-                        float q[4];
+                    for (int nt = 0; nt < 2; ++nt) {
+                        float bb[4] = {bias.x, bias.y, bias.z, bias.w};
+                        if (border2[nt]) {
+                            const float4 c = cb[g4 & 1][nt];
+                            bb[0] -= c.x;
+                            bb[1] -= c.y;
+                            bb[2] -= c.z;
+                            bb[3] -= c.w;
+                        }
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            const float h = v[k] + __shfl_xor(v[k], 16);
-                            q[k] = 0.25f * (h + __shfl_xor(h, 1));
+                            float t = fmaf(accm[mt][nt][4 * g4 + k], p.acc_scale, bb[k]);
+                            if (bn) t = fmaf(fmaxf(t, 0.f), ss[k], tt[k]);
+                            v[nt][k] = t;
                         }
-                        if (tile_ok && (li & 17) == 0) {
-                            const int cg = n0 + cl;
-                            char* prow = p.pool + ((((size_t)bs * Hp + (yl >> 1)) * Wp + (wcol >> 1)) * p.pool_cstride + p.pool_coff) * 4;
-                            split_store4(prow + (size_t)(cg >> 3) * 32, (cg & 7) * 2, q[0], q[1], q[2], q[3]);
+                        uint2 ph, plo;
+                        lm_split4(v[nt][0], v[nt][1], v[nt][2], v[nt][3], &ph, &plo);
+                        gmax = lm_pk_absmax_u16(lm_pk_absmax_u16(gmax, ph.x), ph.y);
+                        char* d = hstage + (nt * 32 + li) * HSTR + ((cl & 31) >> 3) * 32 + (cl & 7) * 2;
+                        *reinterpret_cast<uint2_a*>(d) = ph;
+                        *reinterpret_cast<uint2_a*>(d + 16) = plo;
+                        if (G16 && p.pool != nullptr) {  // both pool partners are in this N-tile: lane^16 (y+1) and lane^1 (x+1)
+                            float q[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float h = v[nt][k] + __shfl_xor(v[nt][k], 16);
+                                q[k] = 0.25f * (h + __shfl_xor(h, 1));
+                            }
+                            if (ok2[nt] && (li & 17) == 0) {
+                                const int cg = n0 + cl;
+                                char* prow = p.pool + ((((size_t)bs * Hp + (yl2[nt] >> 1)) * Wp + (wcol >> 1)) * p.pool_cstride + p.pool_coff) * 4;
+                                split_store4(prow + (size_t)(cg >> 3) * 32, (cg & 7) * 2, q[0], q[1], q[2], q[3]);
+                            }
+                        }
+                    }
+                    if (!G16 && p.pool != nullptr) {  // avg_pool2d(2): rows yb, yb+1 summed first, then x+1 = lane^1
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float pl = v[0][k] + v[1][k];
+                            qs[g4][k] = 0.25f * (pl + lm_lane_xor1(pl));
                         }
                     }
                 }
                 LM_TRACE_SUB(5);
-                // the wave's own 32 pixels x 256 B are now in LDS (same-wave LDS ops are ordered): stream them out.
-                // G32: 32 consecutive pixels of one image row; G16 (W == 16): two consecutive 16-pixel rows = 32 consecutive pixels.
+                // the wave's own 64 pixels x 128 B are now in LDS (same-wave LDS ops are ordered): stream them out, a 128-byte
+                // line per pixel and pass, 16 bytes per lane
                 lm_wave_lds_fence();
-                if (tile_ok) {
-                    const int y_first = G16 ? yb + 2 * nt : yb + nt;
-                    char* orow = p.out + ((((size_t)bs * p.H + y_first) * p.W + x0) * p.out_cstride + p.out_coff + n0) * 4;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int q = i * 64 + lane, px = q >> 4, part = q & 15;
-                        const uint4 val = *reinterpret_cast<const uint4_a*>(stage + px * PSTR + part * 16);
-                        *reinterpret_cast<uint4_a*>(orow + (size_t)px * p.out_cstride * 4 + part * 16) = val;
+                for (int i = 0; i < 8; ++i) {
+                    const int q = i * 64 + lane, px = q >> 3, part = q & 7;
+                    if (ok2[i >> 2]) {
+                        const uint4 val = *reinterpret_cast<const uint4_a*>(hstage + px * HSTR + part * 16);
+                        *reinterpret_cast<uint4_a*>(obase[i >> 2] + (size_t)(px & 31) * p.out_cstride * 4 + mt * 128 + part * 16) = val;
                     }
                 }
-                lm_wave_lds_fence();  // the staging rows are rewritten by the next row
+                lm_wave_lds_fence();  // the staging rows are rewritten by the pooled values / the next pass
                 LM_TRACE_SUB(6);
-            }
-            if (!G16 && p.pool != nullptr) {  // avg_pool2d(2): rows yb, yb+1 summed above; x+1 is lane^1
-                // The wave's pooled output is ONE row of 16 pixels x 64 channels = 16 x 256 B.  It goes through the staging rows
-                // like the full-resolution output (the even lanes' 8-byte pieces straight to memory were 16 scattered stores
-                // at a 256-byte stride per wave -- ~4.7 k cycles per item in the in-kernel timeline, four layers of the network).
+                if (!G16 && p.pool != nullptr) {
+                    // The wave's pooled output of this pass is ONE row of 16 pixels x 32 channels.  It goes through the staging rows
+                    // like the full-resolution output (the even lanes' 8-byte pieces straight to memory were 16 scattered stores
+                    // at a 256-byte stride per wave -- ~4.7 k cycles per item in the in-kernel timeline, four layers of the network).
 #pragma unroll
-                for (int mg = 0; mg < 8; ++mg) {
-                    const int cl = H3P_EPI_CL(mg);
-                    float q[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) q[k] = 0.25f * (pl[mg][k] + lm_lane_xor1(pl[mg][k]));
-                    uint2 ph, plo;
-                    lm_split4(q[0], q[1], q[2], q[3], &ph, &plo);
-                    if ((li & 1) == 0) {
-                        char* d = stage + (li >> 1) * PSTR + (cl >> 3) * 32 + (cl & 7) * 2;
-                        *reinterpret_cast<uint2_a*>(d) = ph;
-                        *reinterpret_cast<uint2_a*>(d + 16) = plo;
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int cl = H3P_EPI_CL(4 * mt + g4);
+                        uint2 ph, plo;
+                        lm_split4(qs[g4][0], qs[g4][1], qs[g4][2], qs[g4][3], &ph, &plo);
+                        if ((li & 1) == 0) {
+                            char* d = hstage + (li >> 1) * HSTR + ((cl & 31) >> 3) * 32 + (cl & 7) * 2;
+                            *reinterpret_cast<uint2_a*>(d) = ph;
+                            *reinterpret_cast<uint2_a*>(d + 16) = plo;
+                        }
                     }
-                }
-                lm_wave_lds_fence();
-                if (bs < p.B && yb + 1 < p.H) {
-                    char* prow = p.pool + ((((size_t)bs * Hp + (yb >> 1)) * Wp + (x0 >> 1)) * p.pool_cstride + p.pool_coff + n0) * 4;
+                    lm_wave_lds_fence();
+                    if (bs < p.B && yb + 1 < p.H) {
+                        char* prow = p.pool + ((((size_t)bs * Hp + (yb >> 1)) * Wp + (x0 >> 1)) * p.pool_cstride + p.pool_coff + n0) * 4;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int q = i * 64 + lane, px = q >> 4, part = q & 15;
-                        const uint4 val = *reinterpret_cast<const uint4_a*>(stage + px * PSTR + part * 16);
-                        *reinterpret_cast<uint4_a*>(prow + (size_t)px * p.pool_cstride * 4 + part * 16) = val;
+                        for (int i = 0; i < 2; ++i) {
+                            const int q = i * 64 + lane, px = q >> 3, part = q & 7;
+                            const uint4 val = *reinterpret_cast<const uint4_a*>(hstage + px * HSTR + part * 16);
+                            *reinterpret_cast<uint4_a*>(prow + (size_t)px * p.pool_cstride * 4 + mt * 128 + part * 16) = val;
+                        }
                     }
+                    lm_wave_lds_fence();
                 }
-                lm_wave_lds_fence();
             }
             }  // stored-output epilogue
             if (p.range_flag != nullptr && lm_pk_out_of_f16_guard(gmax)) atomicOr(p.range_flag, 1u);

@@ -74,6 +74,7 @@ int main(int argc, char** argv) {
         float* corr = nullptr;  // the product runs every 3x3 conv with a border-correction table (deferred BatchNorm shift)
         CK(hipMalloc(&corr, 16 * s.Cout * 4));
         fill_f32<<<16, 256>>>(corr, 16 * (size_t)s.Cout, -0.05f, 0.05f, 6u);
+        CK(hipMemset(corr, 0, s.Cout * 4));  // mask 0 (interior pixel) carries no correction, as in the product
         lm::ConvParamsH3 p{};
         p.in = in; p.in_cstride = s.Cin; p.in_coff = 0; p.w = w; p.acc_scale = 1.f; p.bias = bias; p.bn_s = bs; p.bn_t = bt;
         p.out = out; p.out_cstride = s.Cout; p.out_coff = 0; p.pool = pool; p.pool_cstride = s.Cout; p.pool_coff = 0; p.zeros = zeros;
