@@ -2,9 +2,10 @@
 on the MI355X engine.  Same flags; thin by design (all I/O, off the hot path):
 
 * `.npy` / `.npz`, NIfTI-1 (`.nii`, `.nii.gz`), MetaImage (`.mha`, `.mhd`) and uncompressed DICOM (files and series
-  folders) are read -- and all but DICOM written -- by `volume_io.py` without any imaging dependency;
-* every other format goes through SimpleITK like the reference (imported lazily; this image does not ship it),
-  including the DICOM tag carry-over of `--removemetadata`'s complement;
+  folders) are read and written by `volume_io.py` without any imaging dependency -- DICOM output as one multi-frame file
+  with the carried-over study / patient tags of __main__.py:125-141 (`--removemetadata` drops them);
+* every other format (NRRD, compressed DICOM, ...) goes through SimpleITK like the reference (imported lazily; this image
+  does not ship it);
 * `--cpu` is an error by default (there is no CPU path in this engine); with LUNGMASK_AMD_ALLOW_CPU_FLAG=1 it is accepted, warned about, and the work runs on the MI355X.
 """
 import argparse

@@ -585,6 +585,95 @@ def _read_series(files: List[str]) -> Volume:
 
 
 # ------------------------------------------------------------------------------------------------
+# DICOM writer (__main__.py:119-144 through sitk.ImageFileWriter / GDCM in the reference)
+# ------------------------------------------------------------------------------------------------
+# VR of the elements this writer emits or carries over (utils.py:17-30's list + what __main__.py:136-141 sets)
+_WRITE_VR = {
+    (0x0008, 0x0008): b"CS", (0x0008, 0x0016): b"UI", (0x0008, 0x0018): b"UI", (0x0008, 0x0020): b"DA", (0x0008, 0x0030): b"TM",
+    (0x0008, 0x0050): b"SH", (0x0008, 0x0060): b"CS", (0x0008, 0x0064): b"CS", (0x0008, 0x0090): b"PN", (0x0008, 0x1030): b"LO",
+    (0x0008, 0x103E): b"LO", (0x0010, 0x0010): b"PN", (0x0010, 0x0020): b"LO", (0x0010, 0x0030): b"DA", (0x0010, 0x0040): b"CS",
+    (0x0018, 0x0050): b"DS", (0x0018, 0x0088): b"DS", (0x0018, 0x5100): b"CS", (0x0020, 0x000D): b"UI", (0x0020, 0x000E): b"UI",
+    (0x0020, 0x0010): b"SH", (0x0020, 0x0011): b"IS", (0x0020, 0x0013): b"IS", (0x0020, 0x0032): b"DS", (0x0020, 0x0037): b"DS",
+    (0x0028, 0x0002): b"US", (0x0028, 0x0004): b"CS", (0x0028, 0x0008): b"IS", (0x0028, 0x0010): b"US", (0x0028, 0x0011): b"US",
+    (0x0028, 0x0030): b"DS", (0x0028, 0x0100): b"US", (0x0028, 0x0101): b"US", (0x0028, 0x0102): b"US", (0x0028, 0x0103): b"US",
+    (0x0028, 0x1050): b"DS", (0x0028, 0x1051): b"DS", (0x0028, 0x1052): b"DS", (0x0028, 0x1053): b"DS",
+}
+
+
+def _new_uid(*parts) -> str:
+    """A DICOM UID under the UUID-derived root 2.25 (PS3.5 B.2), deterministic in `parts`."""
+    import hashlib
+
+    return "2.25." + str(int.from_bytes(hashlib.sha256("|".join(str(x) for x in parts).encode()).digest()[:16], "big"))
+
+
+def _ds(x: float) -> str:
+    s = repr(float(x))
+    return s if len(s) <= 16 else f"{x:.10g}"
+
+
+def _encode_element(g: int, e: int, vr: bytes, value: bytes) -> bytes:
+    if len(value) & 1:  # even length: UIDs are padded with NUL, text with a space
+        value += b"\0" if vr == b"UI" else (b" " if vr in _TEXT_VR else b"\0")
+    if vr in _LONG_VR:
+        return struct.pack("<HH2sHI", g, e, vr, 0, len(value)) + value
+    return struct.pack("<HH2sH", g, e, vr, len(value)) + value
+
+
+def write_dicom(path: str, vol: Volume, keep_meta: Optional[Dict[str, str]] = None) -> None:
+    """One explicit-VR little-endian file holding the whole label volume as a multi-frame image (what ITK's GDCM writer
+    produces for a 3-D image under a single file name, __main__.py:122-144): 8-bit unsigned frames in file order, the
+    geometry of `vol` (ImagePositionPatient of frame 0, ImageOrientationPatient, PixelSpacing, SpacingBetweenSlices), and
+    `keep_meta` -- the carried-over study/patient tags plus Series Description and window (keys "gggg|eeee").  The Study
+    Instance UID is the input's when it was kept (SetKeepOriginalImageUID), otherwise new; series / instance UIDs are new.
+    Integer volumes up to 16 bits are written at their width; the reference writes uint8 label volumes."""
+    a = np.ascontiguousarray(vol.array)
+    if a.dtype == np.uint8 or a.dtype == np.bool_:
+        a, bits, signed = a.astype(np.uint8), 8, 0
+    elif a.dtype.kind in "iu" and a.dtype.itemsize <= 2:
+        a, bits, signed = a.astype("<i2" if a.dtype.kind == "i" else "<u2"), 16, int(a.dtype.kind == "i")
+    else:
+        raise DicomError(f"write_dicom: {a.dtype} volumes are not supported (label volumes are uint8)")
+    n, rows, cols = a.shape
+    meta = {k.lower(): v for k, v in (keep_meta or {}).items()}
+    study_uid = (meta.get("0020|000d") or "").strip("\0 ") or _new_uid("study", vol.origin, a.shape)
+    series_uid = _new_uid("series", study_uid, os.path.abspath(path))
+    sop_uid = _new_uid("instance", series_uid)
+    sop_class = "1.2.840.10008.5.1.4.1.1.7.2" if bits == 8 else "1.2.840.10008.5.1.4.1.1.7.3"  # multi-frame grayscale byte / word SC
+    d = np.asarray(vol.direction, dtype=np.float64).reshape(3, 3)
+    el: Dict[Tuple[int, int], bytes] = {
+        (0x0008, 0x0008): b"DERIVED\\SECONDARY", (0x0008, 0x0016): sop_class.encode(), (0x0008, 0x0018): sop_uid.encode(),
+        (0x0008, 0x0060): b"OT", (0x0008, 0x0064): b"WSD", (0x0020, 0x000D): study_uid.encode(), (0x0020, 0x000E): series_uid.encode(),
+        (0x0020, 0x0011): b"1", (0x0020, 0x0013): b"1",
+        (0x0020, 0x0032): "\\".join(_ds(v) for v in vol.origin).encode(),
+        (0x0020, 0x0037): "\\".join(_ds(v) for v in list(d[:, 0]) + list(d[:, 1])).encode(),
+        (0x0018, 0x0088): _ds(vol.spacing[2]).encode(), (0x0018, 0x0050): _ds(vol.spacing[2]).encode(),
+        (0x0028, 0x0002): struct.pack("<H", 1), (0x0028, 0x0004): b"MONOCHROME2", (0x0028, 0x0008): str(n).encode(),
+        (0x0028, 0x0010): struct.pack("<H", rows), (0x0028, 0x0011): struct.pack("<H", cols),
+        (0x0028, 0x0030): (_ds(vol.spacing[1]) + "\\" + _ds(vol.spacing[0])).encode(),  # row spacing \ column spacing
+        (0x0028, 0x0100): struct.pack("<H", bits), (0x0028, 0x0101): struct.pack("<H", bits), (0x0028, 0x0102): struct.pack("<H", bits - 1),
+        (0x0028, 0x0103): struct.pack("<H", signed), (0x0028, 0x1052): b"0", (0x0028, 0x1053): b"1",
+    }
+    for key, val in meta.items():  # carried-over / caller-set tags win over the defaults above, except the image description
+        try:
+            g, e = (int(x, 16) for x in key.split("|"))
+        except ValueError:
+            continue
+        if (g, e) in _WRITE_VR and _WRITE_VR[(g, e)] in _TEXT_VR and (g, e) not in ((0x0008, 0x0016), (0x0008, 0x0018), (0x0020, 0x000E)):
+            el[(g, e)] = str(val).rstrip("\0").encode("latin-1", "replace")
+    body = b"".join(_encode_element(g, e, _WRITE_VR[(g, e)], v) for (g, e), v in sorted(el.items()))
+    pix = a.tobytes()
+    body += struct.pack("<HH2sHI", 0x7FE0, 0x0010, b"OB" if bits == 8 else b"OW", 0, len(pix) + (len(pix) & 1)) + pix + (b"\0" if len(pix) & 1 else b"")
+    fm = b"".join([
+        _encode_element(0x0002, 0x0001, b"OB", b"\x00\x01"), _encode_element(0x0002, 0x0002, b"UI", sop_class.encode()),
+        _encode_element(0x0002, 0x0003, b"UI", sop_uid.encode()), _encode_element(0x0002, 0x0010, b"UI", b"1.2.840.10008.1.2.1"),
+        _encode_element(0x0002, 0x0012, b"UI", _new_uid("lungmask_amd implementation").encode()),
+    ])
+    with open(path, "wb") as f:
+        f.write(b"\0" * 128 + b"DICM" + _encode_element(0x0002, 0x0000, b"UL", struct.pack("<I", len(fm))) + fm + body)
+
+
+# ------------------------------------------------------------------------------------------------
 # front door (utils.load_input_image, utils.py:233-269; writer of __main__.py:119-144)
 # ------------------------------------------------------------------------------------------------
 def _kind(path: str) -> str:
@@ -646,7 +735,9 @@ def save_image(path: str, vol: Volume, keep_meta: Dict[str, str] = None) -> None
         write_nifti(path, vol)
     elif kind == "meta":
         write_metaimage(path, vol)
-    else:  # DICOM, NRRD, ...: the reference's writer
+    elif kind == "dicom":
+        write_dicom(path, vol, keep_meta)
+    else:  # NRRD, ...: the reference's writer
         import SimpleITK as sitk
 
         out = sitk.GetImageFromArray(vol.array)

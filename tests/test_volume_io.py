@@ -212,3 +212,42 @@ def test_reference_dicom_fixtures():
     for k, name in enumerate(sorted(os.listdir("/root/reference/tests/testdata"))):
         raw = np.fromfile(os.path.join("/root/reference/tests/testdata", name), dtype="<i2", count=512 * 512, offset=910).reshape(512, 512)
         assert any(np.array_equal(v.array[j], raw) for j in range(2))
+
+
+def test_dicom_writer_roundtrip_and_tag_carry_over(tmp_path):
+    """__main__.py:119-144 without SimpleITK: the label volume goes out as one explicit-VR little-endian multi-frame file with the
+    input's geometry, the carried-over study / patient tags (utils.py:17-30), the original Study Instance UID
+    (SetKeepOriginalImageUID), 'Created with lungmask' and the 1 / 2 window; series and instance UIDs are new."""
+    from lungmask_amd.__main__ import DICOM_METADATA_TO_KEEP
+
+    rng = np.random.default_rng(3)
+    lab = rng.integers(0, 6, (7, 24, 18)).astype(np.uint8)
+    direction = np.array([[0.0, 1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, -1.0]])
+    in_meta = {"0008|0020": "20240131", "0010|0010": "DOE^JANE", "0010|0020": "ID-7", "0020|000d": "1.2.826.0.1.3680043.8.498.1",
+               "0020|0010": "S1", "0018|5100": "FFS", "0008|0070": "SomeVendor", "0020|000e": "1.2.3.999"}
+    image = vio.Volume(np.zeros_like(lab, dtype=np.int16), (0.7, 0.8, 2.5), (10.0, -20.5, 33.25), direction, in_meta)
+    keep = {k: v for k, v in image.meta.items() if k in DICOM_METADATA_TO_KEEP}  # as lungmask_amd/__main__.py builds it
+    keep.update({"0008|103e": "Created with lungmask", "0028|1050": "1", "0028|1051": "2"})
+    out = tmp_path / "mask.dcm"
+    vio.save_image(str(out), image.like(lab), keep)
+    raw = out.read_bytes()
+    assert raw[128:132] == b"DICM"
+    tags, pixels, tsuid = vio.parse_dicom(raw)
+    assert tsuid == "1.2.840.10008.1.2.1" and len(pixels) == lab.size
+    got = vio.load_input_image(str(out))
+    assert np.array_equal(got.array, lab) and got.array.shape == lab.shape
+    assert np.allclose(got.spacing, image.spacing) and np.allclose(got.origin, image.origin) and np.allclose(got.direction, direction)
+    m = {k: v.strip() for k, v in got.meta.items()}
+    for k in ("0008|0020", "0010|0010", "0010|0020", "0020|000d", "0020|0010", "0018|5100"):
+        assert m[k] == in_meta[k], k
+    assert m["0008|103e"] == "Created with lungmask" and m["0028|1050"] == "1" and m["0028|1051"] == "2"
+    assert "0008|0070" not in m                       # not in the keep list
+    assert m["0020|000e"] != in_meta["0020|000e"]      # a new series
+    assert m["0028|0008"] == "7" and m["0008|0016"] == "1.2.840.10008.5.1.4.1.1.7.2"
+    # --removemetadata: nothing carried over, a fresh study
+    vio.save_image(str(tmp_path / "anon.dcm"), image.like(lab), None)
+    m2 = {k: v.strip() for k, v in vio.load_input_image(str(tmp_path / "anon.dcm")).meta.items()}
+    assert "0010|0010" not in m2 and m2["0020|000d"] != in_meta["0020|000d"] and m2["0020|000d"].startswith("2.25.")
+    # every element has an even length and the tags are in ascending order (PS3.5 7.1)
+    keys = [k for k in tags if k[0] > 2]
+    assert keys == sorted(keys) and all(len(v[1]) % 2 == 0 for v in tags.values())
