@@ -117,12 +117,15 @@ struct HostBuf {
 };
 
 struct PostWorkspace {
-    HostBuf h_area, h_labval, h_recs;
+    HostBuf h_area, h_labval, h_recs, h_scalars;
+    // what the previous volume needed: sizes the tables and the speculative read-back of the next one (postprocess)
+    int last_regions = 0;
+    unsigned last_records = 0;
     DevBuf parent, ids, rank, bgparent, blockcnt, area, labval, recs, lut, mapped, bg, out, scalars, bbox;
     void release() {
         parent.release(); ids.release(); rank.release(); bgparent.release(); blockcnt.release(); area.release(); labval.release();
         recs.release(); lut.release(); mapped.release(); bg.release(); out.release(); scalars.release(); bbox.release();
-        h_area.release(); h_labval.release(); h_recs.release();
+        h_area.release(); h_labval.release(); h_recs.release(); h_scalars.release();
     }
 };
 
@@ -261,7 +264,13 @@ int forward_batches(lm_engine* e, int slot, const float* x, int n, int H, int W,
 int forward_guarded(lm_engine* e, int slot, const float* x, int n, int H, int W, int batch, uint8_t* labels, float* logp);
 // the check alone, for callers that enqueue several forward_batches first (post_engine.hip: inference)
 int forward_range_check(lm_engine* e, int slot, bool* tripped);
-int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spare, int n_spare, int skip_below);
+// range_slot >= 0: the f16 range flag of the forward that produced `lab` is read back in the SAME round trip as the region
+// count (instead of a synchronisation of its own before the call); when it is set, *range_tripped = true, the model of that
+// slot is pinned to the exact-fp32 kernels and nothing else is done (the caller repeats forward + post-processing).
+int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spare, int n_spare, int skip_below, int range_slot = -1,
+                bool* range_tripped = nullptr);
+// bookkeeping of a range flag value that has already been read back into e->range_flag_host
+int range_flag_consume(lm_engine* e, int slot, bool* tripped);
 struct BoundaryRec;
 void replay_merge(int R, const int* area, const uint8_t* lv, const BoundaryRec* recs, size_t nrecs, const std::vector<int>& spare, int skip_below,
                   std::vector<uint8_t>& lut, PostInfo& info);

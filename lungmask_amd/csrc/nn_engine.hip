@@ -602,7 +602,14 @@ int forward_range_check(lm_engine* e, int slot, bool* tripped) {
     if (!h3 || e->range_flag == nullptr) return LM_OK;
     LM_HIP(hipMemcpyAsync(e->range_flag_host, e->range_flag, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
     LM_HIP(hipStreamSynchronize(e->stream));
-    if (*e->range_flag_host == 0) return LM_OK;
+    return range_flag_consume(e, slot, tripped);
+}
+
+// The flag value is in e->range_flag_host (copied behind the forward and waited for by the caller).
+int range_flag_consume(lm_engine* e, int slot, bool* tripped) {
+    *tripped = false;
+    Model& md = e->models[slot];
+    if (e->range_flag_host == nullptr || *e->range_flag_host == 0) return LM_OK;
     LM_HIP(hipMemsetAsync(e->range_flag, 0, sizeof(unsigned), e->stream));
     *e->range_flag_host = 0;
     md.force_f32 = true;
@@ -619,6 +626,9 @@ int forward_guarded(lm_engine* e, int slot, const float* x, int n, int H, int W,
         set_error("model slot %d is empty", slot);
         return LM_ERR_NOMODEL;
     }
+    // a flag left behind by a forward that was never checked (an error return, a call site without a check) must not be
+    // attributed to this model
+    if (e->range_flag != nullptr) LM_HIP(hipMemsetAsync(e->range_flag, 0, sizeof(unsigned), e->stream));
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (logp != nullptr || batch <= 0) LM_TRY(forward(e, slot, x, n, H, W, labels, logp));
         else LM_TRY(forward_batches(e, slot, x, n, H, W, batch, labels));

@@ -138,7 +138,8 @@ void replay_merge(int R, const int* area, const uint8_t* lv, const BoundaryRec* 
     }
 }
 
-int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spare_p, int n_spare, int skip_below) {
+int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spare_p, int n_spare, int skip_below, int range_slot, bool* range_tripped) {
+    if (range_tripped) *range_tripped = false;
     if (N <= 0 || H <= 0 || W <= 0) return LM_OK;
     const Dims d{N, H, W};
     const size_t nvox = d.nvox();
@@ -176,47 +177,82 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
         ProfScope ps(e, "post_rank_relabel", (double)nvox * 16);
         LM_K(ccl_rank(parent, ws.rank.as<int>(), ids, ws.blockcnt.as<int>(), total_dev, nvox, s));
     }
+    // ---- (2)-(3) run BEFORE the host knows this volume's region count: the tables are sized from the previous volume (what it
+    // needed + a margin; the kernels ignore ids / records beyond the capacity and the host repeats a pass whose guess was too
+    // small), and ONE read-back delivers the region count, the record count, the f16 range flag of the forward that produced the
+    // labels (range_slot) and the first `guess` entries of the three tables -- normally all of them.  (Round 2 synchronised four
+    // times here: range flag, region count, record count, tables.)
+    const bool want_range = range_slot >= 0 && range_tripped != nullptr && e->range_flag != nullptr && e->precision == 1 && !e->models[range_slot].force_f32;
+    LM_TRY(ws.h_scalars.reserve(64));
+    volatile int* hs = ws.h_scalars.as<int>();  // [0] regions, [1] records
+    int rcap = std::max(16384, ws.last_regions + ws.last_regions / 2 + 1024);
+    unsigned cap = (unsigned)std::min<size_t>(nvox, std::max<size_t>(ws.recs.cap / sizeof(BoundaryRec), 1u << 20));
     int R = 0;
-    LM_HIP(hipMemcpyAsync(&R, total_dev, sizeof(int), hipMemcpyDeviceToHost, s));
-    LM_HIP(hipStreamSynchronize(s));
-    info.regions = R;
+    unsigned nrec = 0;
     std::vector<uint8_t> lut(1, 0);
-    if (R > 0) {
+    const int* area = nullptr;
+    const uint8_t* lv = nullptr;
+    const BoundaryRec* recs = nullptr;
+    for (int attempt = 0;; ++attempt) {
+        rcap = (int)std::min<size_t>((size_t)rcap, nvox);
+        LM_TRY(ws.area.reserve(((size_t)rcap + 1) * 4));
+        LM_TRY(ws.labval.reserve((size_t)rcap + 1));
+        LM_TRY(ws.recs.reserve((size_t)cap * sizeof(BoundaryRec)));
         // ---- (2) regionprops: area + label value                                           utils.py:298
-        LM_TRY(ws.area.reserve(((size_t)R + 1) * 4));
-        LM_TRY(ws.labval.reserve((size_t)R + 1));
-        LM_HIP(hipMemsetAsync(ws.area.p, 0, ((size_t)R + 1) * 4, s));
-        LM_HIP(hipMemsetAsync(ws.labval.p, 0, (size_t)R + 1, s));
+        LM_HIP(hipMemsetAsync(ws.area.p, 0, ((size_t)rcap + 1) * 4, s));
+        LM_HIP(hipMemsetAsync(ws.labval.p, 0, (size_t)rcap + 1, s));
         {
             ProfScope ps(e, "post_region_stats", (double)nvox * 5);
-            LM_K(region_stats(ids, lab, ws.area.as<int>(), ws.labval.as<uint8_t>(), nvox, s));
+            LM_K(region_stats(ids, lab, ws.area.as<int>(), ws.labval.as<uint8_t>(), nvox, s, rcap));
         }
         // ---- (3) boundary voxels between regions (the only voxels the merge loop can ever count)
-        unsigned cap = (unsigned)std::min<size_t>(nvox, std::max<size_t>(ws.recs.cap / sizeof(BoundaryRec), 1u << 20));
-        unsigned nrec = 0;
-        for (;;) {
-            LM_TRY(ws.recs.reserve((size_t)cap * sizeof(BoundaryRec)));
-            LM_HIP(hipMemsetAsync(count_dev, 0, sizeof(unsigned), s));
-            {
-                ProfScope ps(e, "post_boundary_records", (double)nvox * 4);
-                LM_K(boundary_records(ids, d, ws.recs.as<BoundaryRec>(), count_dev, cap, s));
-            }
-            LM_HIP(hipMemcpyAsync(&nrec, count_dev, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-            LM_HIP(hipStreamSynchronize(s));
-            if (nrec <= cap) break;
-            cap = nrec;  // rare: grow and redo
+        LM_HIP(hipMemsetAsync(count_dev, 0, sizeof(unsigned), s));
+        {
+            ProfScope ps(e, "post_boundary_records", (double)nvox * 4);
+            LM_K(boundary_records(ids, d, ws.recs.as<BoundaryRec>(), count_dev, cap, s));
         }
-        info.boundary_records = nrec;
-        LM_TRY(ws.h_area.reserve(((size_t)R + 1) * 4));
-        LM_TRY(ws.h_labval.reserve((size_t)R + 1));
-        LM_TRY(ws.h_recs.reserve(std::max<size_t>((size_t)nrec * sizeof(BoundaryRec), 64)));
-        const int* area = ws.h_area.as<int>();
-        const uint8_t* lv = ws.h_labval.as<uint8_t>();
-        const BoundaryRec* recs = ws.h_recs.as<BoundaryRec>();
-        LM_HIP(hipMemcpyAsync(ws.h_area.p, ws.area.p, ((size_t)R + 1) * 4, hipMemcpyDeviceToHost, s));
-        LM_HIP(hipMemcpyAsync(ws.h_labval.p, ws.labval.p, (size_t)R + 1, hipMemcpyDeviceToHost, s));
-        if (nrec) LM_HIP(hipMemcpyAsync(ws.h_recs.p, ws.recs.p, (size_t)nrec * sizeof(BoundaryRec), hipMemcpyDeviceToHost, s));
+        // speculative read-back
+        const size_t g_r = (size_t)std::min(rcap, std::max(4096, ws.last_regions + ws.last_regions / 4 + 256));
+        const size_t g_n = std::min<size_t>(cap, std::max<size_t>(32768, (size_t)ws.last_records + ws.last_records / 4 + 1024));
+        LM_TRY(ws.h_area.reserve((g_r + 1) * 4));
+        LM_TRY(ws.h_labval.reserve(g_r + 1));
+        LM_TRY(ws.h_recs.reserve(g_n * sizeof(BoundaryRec)));
+        LM_HIP(hipMemcpyAsync(ws.h_scalars.p, total_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, s));  // total_dev, count_dev are neighbours
+        if (want_range && attempt == 0) LM_HIP(hipMemcpyAsync(e->range_flag_host, e->range_flag, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        LM_HIP(hipMemcpyAsync(ws.h_area.p, ws.area.p, (g_r + 1) * 4, hipMemcpyDeviceToHost, s));
+        LM_HIP(hipMemcpyAsync(ws.h_labval.p, ws.labval.p, g_r + 1, hipMemcpyDeviceToHost, s));
+        LM_HIP(hipMemcpyAsync(ws.h_recs.p, ws.recs.p, g_n * sizeof(BoundaryRec), hipMemcpyDeviceToHost, s));
         LM_HIP(hipStreamSynchronize(s));
+        if (want_range && attempt == 0) {
+            LM_TRY(range_flag_consume(e, range_slot, range_tripped));
+            if (*range_tripped) return LM_OK;
+        }
+        R = hs[0];
+        nrec = (unsigned)hs[1];
+        if (R > rcap || nrec > cap) {  // rare: a table was too small -- grow and repeat both passes
+            rcap = std::max(rcap, R);
+            cap = std::max(cap, nrec);
+            continue;
+        }
+        if ((size_t)R > g_r || nrec > g_n) {  // the tables are complete on the device, the guess of what to fetch was short (first volume)
+            LM_TRY(ws.h_area.reserve(((size_t)R + 1) * 4));
+            LM_TRY(ws.h_labval.reserve((size_t)R + 1));
+            LM_TRY(ws.h_recs.reserve(std::max<size_t>((size_t)nrec * sizeof(BoundaryRec), 64)));
+            LM_HIP(hipMemcpyAsync(ws.h_area.p, ws.area.p, ((size_t)R + 1) * 4, hipMemcpyDeviceToHost, s));
+            LM_HIP(hipMemcpyAsync(ws.h_labval.p, ws.labval.p, (size_t)R + 1, hipMemcpyDeviceToHost, s));
+            if (nrec) LM_HIP(hipMemcpyAsync(ws.h_recs.p, ws.recs.p, (size_t)nrec * sizeof(BoundaryRec), hipMemcpyDeviceToHost, s));
+            LM_HIP(hipStreamSynchronize(s));
+        }
+        break;
+    }
+    ws.last_regions = R;
+    ws.last_records = nrec;
+    info.regions = R;
+    info.boundary_records = nrec;
+    area = ws.h_area.as<int>();
+    lv = ws.h_labval.as<uint8_t>();
+    recs = ws.h_recs.as<BoundaryRec>();
+    if (R > 0) {
         // ---- (4) the sequential merge on the region graph                                  utils.py:299-342
         const auto t0 = std::chrono::steady_clock::now();
         replay_merge(R, area, lv, recs, nrec, spare, skip_below, lut, info);
@@ -313,6 +349,8 @@ int inference(lm_engine* e, int slot, const void* vol, int dtype, int n, int h, 
     // and forward run meanwhile.
     const int esz = dtype == LM_I16 ? 2 : ((dtype == LM_I32 || dtype == LM_F32) ? 4 : 8);
     const int head = (e->head_slices > 0 && e->head_slices < n) ? e->head_slices : n;
+    // (a flag left behind by a forward that was never checked must not be attributed to this model)
+    if (e->range_flag != nullptr) LM_HIP(hipMemsetAsync(e->range_flag, 0, sizeof(unsigned), e->stream));
     for (int s0 = 0; s0 < n; s0 += (s0 == 0 ? head : n)) {
         const int ns = s0 == 0 ? head : n - s0;
         if (s0 > 0) {
@@ -340,13 +378,16 @@ int inference(lm_engine* e, int slot, const void* vol, int dtype, int n, int h, 
         // for the head's forward before it could enqueue the tail's
         LM_TRY(forward_batches(e, slot, a.xf.as<float>() + (size_t)s0 * R * R, ns, R, R, batch, a.labels.as<uint8_t>() + (size_t)s0 * R * R));
     }
-    {
-        bool tripped = false;
-        LM_TRY(forward_range_check(e, slot, &tripped));
-        if (tripped)  // the model is now pinned to the exact-fp32 kernels: the whole volume again (its pre-processed slices are all there)
-            LM_TRY(forward_guarded(e, slot, a.xf.as<float>(), n, R, R, batch, a.labels.as<uint8_t>(), nullptr));
+    // The f16 range flag of the forward passes is read back once per volume: inside the post-processing's first round trip when
+    // there is one, on its own otherwise.  When it is set the model is now pinned to the exact-fp32 kernels: the whole volume
+    // again (its pre-processed slices are all there).
+    bool tripped = false;
+    if (vol_post) LM_TRY(postprocess(e, a.labels.as<uint8_t>(), n, R, R, nullptr, 0, 3, slot, &tripped));  // mask.py:191-194
+    else LM_TRY(forward_range_check(e, slot, &tripped));
+    if (tripped) {
+        LM_TRY(forward_guarded(e, slot, a.xf.as<float>(), n, R, R, batch, a.labels.as<uint8_t>(), nullptr));
+        if (vol_post) LM_TRY(postprocess(e, a.labels.as<uint8_t>(), n, R, R, nullptr, 0, 3));
     }
-    if (vol_post) LM_TRY(postprocess(e, a.labels.as<uint8_t>(), n, R, R, nullptr, 0, 3));  // mask.py:191-194
     ReshapeParams rs{a.labels.as<uint8_t>(), a.bbox.as<int>(), out, n, R, R, h, w};  // mask.py:196-202
     {
         ProfScope ps(e, "reshape_mask", (double)n * ((double)R * R + (double)h * w));

@@ -28,7 +28,7 @@ hipError_t ccl_label(const uint8_t* lab, int* parent, Dims d, bool conn26, hipSt
 // blockcnt: scratch of >= nblocks(nvox)+1 ints.  total_dev receives the number of components.
 size_t rank_blocks(size_t nvox);
 hipError_t ccl_rank(const int* parent, int* rank, int* ids, int* blockcnt, int* total_dev, size_t nvox, hipStream_t s);
-hipError_t region_stats(const int* ids, const uint8_t* lab, int* area, uint8_t* labval, size_t nvox, hipStream_t s);
+hipError_t region_stats(const int* ids, const uint8_t* lab, int* area, uint8_t* labval, size_t nvox, hipStream_t s, int cap = 0x7fffffff);
 hipError_t boundary_records(const int* ids, Dims d, BoundaryRec* recs, unsigned* count_dev, unsigned cap, hipStream_t s);
 hipError_t apply_lut(const int* ids, const uint8_t* lut, uint8_t* out, size_t nvox, hipStream_t s);
 

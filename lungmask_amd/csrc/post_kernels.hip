@@ -404,10 +404,13 @@ __device__ __forceinline__ void block_run_histogram(size_t nvox, int* table, Key
         if (hkey[i] != H_EMPTY && hcnt[i]) atomicAdd(&table[hkey[i]], hcnt[i]);
 }
 
+// `cap`: regions with an id beyond it are ignored (the host sizes the tables from the previous volume before it knows this
+// volume's region count, and repeats the pass when the guess was too small).
 __global__ __launch_bounds__(TPB) void region_stats_kernel(const int* __restrict__ ids, const uint8_t* __restrict__ lab, int* area,
-                                                           uint8_t* labval, size_t nvox) {
+                                                           uint8_t* labval, size_t nvox, int cap) {
     block_run_histogram(nvox, area, [&](size_t v, bool* counted) {
-        const int id = v < nvox ? ids[v] : 0;
+        int id = v < nvox ? ids[v] : 0;
+        if (id > cap) id = 0;
         *counted = id != 0;
         if (id && ((v & 63) == 0 || ids[v - 1] != id)) labval[id] = lab[v];
         return id;
@@ -792,8 +795,8 @@ hipError_t ccl_rank(const int* parent, int* rank, int* ids, int* blockcnt, int* 
     return hipGetLastError();
 }
 
-hipError_t region_stats(const int* ids, const uint8_t* lab, int* area, uint8_t* labval, size_t nvox, hipStream_t s) {
-    LM_LAUNCH(region_stats_kernel, dim3(grid_for(nvox, 64 * 64, 2048)), dim3(TPB), 0, s, ids, lab, area, labval, nvox);
+hipError_t region_stats(const int* ids, const uint8_t* lab, int* area, uint8_t* labval, size_t nvox, hipStream_t s, int cap) {
+    LM_LAUNCH(region_stats_kernel, dim3(grid_for(nvox, 64 * 64, 2048)), dim3(TPB), 0, s, ids, lab, area, labval, nvox, cap);
     return hipGetLastError();
 }
 

@@ -82,6 +82,7 @@ class LMInferer:
         # stays the default; a fresh 79 MB array per 300-slice volume costs ~3-4 ms of page faults and unmapping.
         self.reuse_output = reuse_output
         self._out = None
+        self._blocks = []  # result memory handed back by the garbage collector (see _result_array)
         if force_cpu:
             # mask.py:118-134 selects torch-CPU.  This engine has no CPU compute path by design, so by default the request is an
             # ERROR -- a caller who asks for the CPU (no usable GPU, reproducing a CPU result) must not silently get GPU execution.
@@ -103,6 +104,23 @@ class LMInferer:
         if self.fillmodel is not None:  # mask.py:136-139
             self.engine.load_state_dict(1, fill_state_dict if fill_state_dict is not None else get_model(self.fillmodel, fillmodel_path))
             self.fill_slot = 1
+
+    def _result_array(self, shape) -> np.ndarray:
+        """A uint8 result array that is the caller's alone -- the reference's contract (mask.py:210) -- without paying for fresh
+        memory on every call: a new 79 MB numpy array costs ~4.7 ms of page faults and unmapping per 300-slice volume (6 % of the
+        call).  The arrays handed out are views of blocks this object keeps; a block is used again only once nothing but this list
+        refers to it any more, i.e. after the previous result AND every view or slice taken from it have been dropped (numpy
+        points all of them at the block itself, so its reference count tells).  While a caller holds on to earlier results, new
+        blocks are allocated exactly as before; at most two idle blocks are retained."""
+        import sys
+
+        n = int(np.prod(shape, dtype=np.int64))
+        for blk in self._blocks:
+            if blk.size == n and sys.getrefcount(blk) <= 3:  # the list, the loop variable, getrefcount's argument
+                return np.ndarray(shape, dtype=np.uint8, buffer=blk)
+        blk = np.empty(n, dtype=np.uint8)
+        self._blocks = [b for b in self._blocks if sys.getrefcount(b) > 3][:1] + [blk] if len(self._blocks) >= 2 else self._blocks + [blk]
+        return np.ndarray(shape, dtype=np.uint8, buffer=blk)
 
     def apply(self, image, out: Optional[np.ndarray] = None) -> np.ndarray:
         """mask.py:212-232 (+ _inference :141-210).  `image`: numpy volume [n,h,w], a `volume_io.Volume`, or a SimpleITK
@@ -140,7 +158,9 @@ class LMInferer:
                 if self._out is None or self._out.shape != tuple(inimg_raw.shape):
                     self._out = np.empty(inimg_raw.shape, dtype=np.uint8)
                 out = self._out
-            # (the labels land in `out` / a fresh array straight from the device: no further host copy)
+            elif out is None and inimg_raw.ndim == 3:
+                out = self._result_array(inimg_raw.shape)
+            # (the labels land in `out` / the result array straight from the device: no further host copy)
             return self.engine.apply(0, inimg_raw, fill_slot=self.fill_slot, batch_size=self.batch_size,
                                      volume_postprocessing=self.volume_postprocessing, out=out)
         else:

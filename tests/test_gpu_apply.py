@@ -181,6 +181,21 @@ def test_force_cpu_raises_unless_opted_in(gpu_engine, tmp_path, monkeypatch):
     assert inf.apply(vol) is b  # the reused buffer
     mine = np.empty(vol.shape, np.uint8)
     assert inf.apply(vol, out=mine) is mine and np.array_equal(mine, a)
+    # default mode: every call returns an array of its own (mask.py:210) -- result memory is recycled only after the caller has
+    # dropped the previous result and every view of it
+    inf2 = LMInferer(modelpath=str(p), tqdm_disable=True)
+    r1 = inf2.apply(vol)
+    view = r1[1]
+    vol2 = po.phantom(2, 512, 512, seed=6)
+    r2 = inf2.apply(vol2)
+    assert r2 is not r1 and not np.shares_memory(r1, r2) and np.array_equal(r1, a) and not np.array_equal(r2, a)
+    addr1 = r1.ctypes.data
+    del r1
+    r3 = inf2.apply(vol2)
+    assert r3.ctypes.data != addr1 and np.array_equal(view, a[1])  # a slice of the first result is still alive and intact
+    del view, r3
+    r4 = inf2.apply(vol)
+    assert np.array_equal(r4, a) and not np.shares_memory(r4, r2)
 
 
 def test_sharded_pipeline_world1_on_torch_cuda_tensors(gpu_engine):
