@@ -62,6 +62,18 @@ __device__ __forceinline__ void lm_wave_lds_fence() {
 #endif
 }
 
+// 16-byte store of streaming output (tensors far larger than the caches, written once): the non-temporal form does not
+// allocate the line in L2 / the memory-side cache on its way out.
+__device__ __forceinline__ void lm_store16_stream(void* dst, uint4 v) {
+#if defined(LM_EMU_BUILD) || defined(LM_NO_NT_STORES)
+    *reinterpret_cast<uint4*>(dst) = v;
+#else
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const u4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<u4*>(dst));
+#endif
+}
+
 // The value of lane ^ 1 (the x + 1 partner of the 2x2 average pool): a DPP quad permutation on the GPU -- a modifier of the
 // consuming VALU instruction or one v_mov_dpp -- instead of __shfl_xor's ds_bpermute_b32 through the LDS crossbar.
 __device__ __forceinline__ float lm_lane_xor1(float v) {

@@ -421,6 +421,10 @@ struct Fwd {
             q.W = W;
             q.Cin = L.cin;
             q.Cout = L.cout;
+            {   // LM_STREAM_OUT_MB: outputs above this size are stored non-temporal (lab hook; default 128 MB)
+                static const double lim_mb = [] { const char* v = getenv("LM_STREAM_OUT_MB"); return v ? atof(v) : 128.0; }();
+                q.stream_out = px * L.cout * 4.0 > lim_mb * 1048576.0 ? 1 : 0;
+            }
             if (head && head->labels && !head->logp && L.taps == 9 && conv3x3_h3_can_fuse_head(q)) {
                 q.head_w = head->w;
                 q.head_b = head->bias;

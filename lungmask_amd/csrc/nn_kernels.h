@@ -82,6 +82,9 @@ struct ConvParamsH3 {
     // tensor ORs 1 into this device word when a value it writes is not below kF16Guard in magnitude (or is not finite);
     // the engine checks the word after the forward and re-runs the model on the exact-fp32 kernels (nn_engine.hip).
     unsigned* range_flag = nullptr;
+    // the output tensor is far larger than the caches (the 256 x 256 and 128 x 128 levels of a 20-slice batch): its stores are
+    // issued non-temporal, so that they do not evict the weights and halo rows the kernel re-reads
+    int stream_out = 0;
 };
 constexpr float kF16Guard = 32768.f;  // 2^15: a factor 2 below the largest finite half
 // whether launch_conv3x3_h3 can take the fused head for this shape (else run launch_head_h3 on the stored output)

@@ -800,7 +800,9 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                     const int q = i * 64 + lane, px = q >> 3, part = q & 7;
                     if (ok2[i >> 2]) {
                         const uint4 val = *reinterpret_cast<const uint4_a*>(hstage + px * HSTR + part * 16);
-                        *reinterpret_cast<uint4_a*>(obase[i >> 2] + (size_t)(px & 31) * p.out_cstride * 4 + mt * 128 + part * 16) = val;
+                        char* dst = obase[i >> 2] + (size_t)(px & 31) * p.out_cstride * 4 + mt * 128 + part * 16;
+                        if (p.stream_out) lm_store16_stream(dst, val);
+                        else *reinterpret_cast<uint4_a*>(dst) = val;
                     }
                 }
                 lm_wave_lds_fence();  // the staging rows are rewritten by the pooled values / the next pass
@@ -978,8 +980,8 @@ __global__ __launch_bounds__(256) void first_conv_h3_kernel(FirstConvParams p) {
             lm_split4(v[4], v[5], v[6], v[7], &h1, &l1);
             gmax = lm_pk_absmax_u16(lm_pk_absmax_u16(lm_pk_absmax_u16(lm_pk_absmax_u16(gmax, h0.x), h0.y), h1.x), h1.y);
             const uint4 hi = {h0.x, h0.y, h1.x, h1.y}, lo = {l0.x, l0.y, l1.x, l1.y};
-            *reinterpret_cast<uint4*>(g) = hi;
-            *reinterpret_cast<uint4*>(g + 16) = lo;
+            lm_store16_stream(g, hi);
+            lm_store16_stream(g + 16, lo);
         }
     }
     if (p.range_flag != nullptr && lm_pk_out_of_f16_guard(gmax)) atomicOr(p.range_flag, 1u);
@@ -1001,51 +1003,76 @@ __device__ __forceinline__ void load_group(const char* g, float* v) {  // 32-byt
 }
 }  // namespace
 
-// Bilinear x2 (align_corners=False) on split tensors; thread = (output pixel, 8-channel group), one block row per output image
-// row (no 64-bit index arithmetic), the 32-byte group written as two 16-byte stores.
+// Bilinear x2 (align_corners=False) on split tensors.  thread = (LOW-resolution pixel (i, j), 8-channel group) and writes the 2 x 2
+// output pixels (2i..2i+1, 2j..2j+1): the 3 x 3 low-resolution neighbourhood is loaded and converted once for four outputs (a
+// thread per output pixel loaded and converted 4 groups per output: the kernel was bound by its conversions, not by HBM), the
+// interpolation is separable -- per source row the two horizontal phases, then the two vertical ones -- with exactly the weights,
+// operands and operation order of the per-output form (out = wya * (wxa * a00 + wxb * a01) + wyb * (wxa * a10 + wxb * a11), edge
+// rows / columns with weights (1, 0) on the clamped index), so the results are bit-identical to it.  One block row per
+// low-resolution image row; a wave writes 2 rows x 64 / G x 2 pixels of 4 * C contiguous bytes each.
 __global__ __launch_bounds__(256) void upsample2x_h3_kernel(UpsampleParams p) {
     const unsigned G = (unsigned)p.C >> 3;
-    const int H2 = 2 * p.h, W2 = 2 * p.w;
-    const unsigned e = blockIdx.x * 256u + threadIdx.x;  // element of the output row: x * G + g
-    if (e >= (unsigned)W2 * G) return;
-    const int x = (int)(e / G), g = (int)(e - (unsigned)x * G);
-    const int y = (int)blockIdx.y, b = (int)blockIdx.z;
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;  // element of the low-resolution row: j * G + g
+    if (e >= (unsigned)p.w * G) return;
+    const int j = (int)(e / G), g = (int)(e - (unsigned)j * G);
+    const int i = (int)blockIdx.y, b = (int)blockIdx.z;
+    const int W2 = 2 * p.w, H2 = 2 * p.h;
     const char* in = reinterpret_cast<const char*>(p.in);
     char* out = reinterpret_cast<char*>(p.out);
-    int ya, yb, xa, xb;
-    float wya, wyb, wxa, wxb;
-    {
-        const int i = y >> 1;
-        if (y & 1) { ya = i; yb = min(i + 1, p.h - 1); wya = 0.75f; wyb = 0.25f; }
-        else if (i == 0) { ya = 0; yb = 0; wya = 1.f; wyb = 0.f; }
-        else { ya = i - 1; yb = i; wya = 0.25f; wyb = 0.75f; }
-        const int j = x >> 1;
-        if (x & 1) { xa = j; xb = min(j + 1, p.w - 1); wxa = 0.75f; wxb = 0.25f; }
-        else if (j == 0) { xa = 0; xb = 0; wxa = 1.f; wxb = 0.f; }
-        else { xa = j - 1; xb = j; wxa = 0.25f; wxb = 0.75f; }
-    }
+    // horizontal taps of the even output column 2j: (xa, xb, wxa, wxb); of the odd one 2j+1: (j, min(j+1, w-1), 0.75, 0.25)
+    const int exa = j == 0 ? 0 : j - 1, exb = j;
+    const float ewa = j == 0 ? 1.f : 0.25f, ewb = j == 0 ? 0.f : 0.75f;
+    const int oxb = min(j + 1, p.w - 1);
+    const int rows[3] = {max(i - 1, 0), i, min(i + 1, p.h - 1)};
     const char* base = in + (size_t)b * p.h * p.w * p.C * 4 + (size_t)g * 32;
-    float a00[8], a01[8], a10[8], a11[8], o[8];
-    load_group(base + ((size_t)ya * p.w + xa) * p.C * 4, a00);
-    load_group(base + ((size_t)ya * p.w + xb) * p.C * 4, a01);
-    load_group(base + ((size_t)yb * p.w + xa) * p.C * 4, a10);
-    load_group(base + ((size_t)yb * p.w + xb) * p.C * 4, a11);
+    float hE[3][8], hO[3][8];  // horizontally interpolated source rows i-1, i, i+1: even / odd output column
 #pragma unroll
-    for (int k = 0; k < 8; ++k) o[k] = wya * (wxa * a00[k] + wxb * a01[k]) + wyb * (wxa * a10[k] + wxb * a11[k]);
-    char* dst = out + ((((size_t)b * H2 + y) * W2 + x) * p.out_cstride + p.out_coff) * 4 + (size_t)g * 32;
-    uint2 h0, l0, h1, l1;
-    lm_split4(o[0], o[1], o[2], o[3], &h0, &l0);
-    lm_split4(o[4], o[5], o[6], o[7], &h1, &l1);
-    const uint4 hi = {h0.x, h0.y, h1.x, h1.y}, lo = {l0.x, l0.y, l1.x, l1.y};
-    *reinterpret_cast<uint4*>(dst) = hi;
-    *reinterpret_cast<uint4*>(dst + 16) = lo;
+    for (int r = 0; r < 3; ++r) {
+        if (r == 0 && i == 0) continue;  // (row i-1 is not used by the first image row: weights (1, 0) on row 0)
+        const char* rowp = base + (size_t)rows[r] * p.w * p.C * 4;
+        float am[8], ac[8], ap[8];
+        load_group(rowp + (size_t)exa * p.C * 4, am);
+        load_group(rowp + (size_t)j * p.C * 4, ac);
+        load_group(rowp + (size_t)oxb * p.C * 4, ap);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            hE[r][k] = ewa * am[k] + ewb * (j == 0 ? am[k] : ac[k]);  // j == 0: both taps are pixel 0 (exa == exb == 0)
+            hO[r][k] = 0.75f * ac[k] + 0.25f * ap[k];
+        }
+    }
+    auto store = [&](int y, int x, const float* o) __attribute__((always_inline)) {
+        char* dst = out + ((((size_t)b * H2 + y) * W2 + x) * p.out_cstride + p.out_coff) * 4 + (size_t)g * 32;
+        uint2 h0, l0, h1, l1;
+        lm_split4(o[0], o[1], o[2], o[3], &h0, &l0);
+        lm_split4(o[4], o[5], o[6], o[7], &h1, &l1);
+        const uint4 hi = {h0.x, h0.y, h1.x, h1.y}, lo = {l0.x, l0.y, l1.x, l1.y};
+        lm_store16_stream(dst, hi);
+        lm_store16_stream(dst + 16, lo);
+    };
+    float o[8];
+    // even output row 2i: (ya, yb, wya, wyb) = i == 0 ? (0, 0, 1, 0) : (i-1, i, 0.25, 0.75)
+    const float eya = i == 0 ? 1.f : 0.25f, eyb = i == 0 ? 0.f : 0.75f;
+    const int ra = i == 0 ? 1 : 0;  // index into hE / hO of the row "ya"
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = eya * hE[ra][k] + eyb * hE[1][k];
+    store(2 * i, 2 * j, o);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = eya * hO[ra][k] + eyb * hO[1][k];
+    store(2 * i, 2 * j + 1, o);
+    // odd output row 2i+1: (i, min(i+1, h-1), 0.75, 0.25)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = 0.75f * hE[1][k] + 0.25f * hE[2][k];
+    store(2 * i + 1, 2 * j, o);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = 0.75f * hO[1][k] + 0.25f * hO[2][k];
+    store(2 * i + 1, 2 * j + 1, o);
 }
 
 hipError_t launch_upsample2x_h3(const UpsampleParams& p, hipStream_t stream) {
     if ((p.C & 7) || (p.out_cstride & 7) || (p.out_coff & 7)) return hipErrorInvalidValue;
-    const unsigned row_elems = (unsigned)(2 * p.w) * (unsigned)(p.C >> 3);
-    if (p.B > 65535 || 2 * p.h > 65535) return hipErrorInvalidValue;
-    LM_LAUNCH(upsample2x_h3_kernel, dim3((row_elems + 255) / 256, (unsigned)(2 * p.h), (unsigned)p.B), dim3(256), 0, stream, p);
+    const unsigned row_elems = (unsigned)p.w * (unsigned)(p.C >> 3);
+    if (p.B > 65535 || p.h > 65535) return hipErrorInvalidValue;
+    LM_LAUNCH(upsample2x_h3_kernel, dim3((row_elems + 255) / 256, (unsigned)p.h, (unsigned)p.B), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 
