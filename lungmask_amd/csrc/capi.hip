@@ -68,6 +68,8 @@ void lm_engine_destroy(lm_engine* e) {
     if (e->range_flag_host) (void)hipHostFree(e->range_flag_host);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     if (e->tail_ready) (void)hipEventDestroy(e->tail_ready);
+    if (e->pre_fork) (void)hipEventDestroy(e->pre_fork);
+    if (e->pre_tail_done) (void)hipEventDestroy(e->pre_tail_done);
     e->nn.release();
     e->nn2.release();
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);

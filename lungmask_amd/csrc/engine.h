@@ -242,6 +242,7 @@ struct lm_engine {
     // slices >= head_slices.  head_slices == 0: the whole volume is already resident (lm_apply_dev).
     hipStream_t copy_stream = nullptr;
     hipEvent_t tail_ready = nullptr;
+    hipEvent_t pre_fork = nullptr, pre_tail_done = nullptr;  // the tail's pre-processing on copy_stream (post_engine.hip: inference)
     int head_slices = 0;
     // set by the copying thread once tail_ready has been recorded (1) or the copy failed (-1): the hot path must not enqueue
     // its wait on an event that has not been recorded yet (that would be a no-op)
@@ -258,7 +259,11 @@ namespace lm {
 int model_load(lm_engine* e, int slot, const lm_tensor* tensors, int n);
 int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t* labels, float* logp, int lane = 0);
 // n slices in batches of `batch` (mask.py:173-187), batches alternating over the engine's forward lanes
-int forward_batches(lm_engine* e, int slot, const float* x, int n, int H, int W, int batch, uint8_t* labels);
+// `gate` (optional): called ONCE on the host right before the first batch that starts at or beyond slice `gate_slice` is
+// enqueued; it returns an event (or nullptr) that every lane waits for before it runs such a batch.  This is how the tail of a
+// volume -- still being copied in / pre-processed on another stream -- joins the batch loop without a join of the lanes.
+int forward_batches(lm_engine* e, int slot, const float* x, int n, int H, int W, int batch, uint8_t* labels, int gate_slice = -1,
+                    const std::function<int(hipEvent_t*)>& gate = nullptr);
 // The two above + the f16 range guard: waits for the forward, and when a split-f16 forward reported activations beyond the f16
 // range, pins the model to the exact-fp32 kernels and runs the forward again.  What the C ABI and lm_apply call.
 int forward_guarded(lm_engine* e, int slot, const float* x, int n, int H, int W, int batch, uint8_t* labels, float* logp);

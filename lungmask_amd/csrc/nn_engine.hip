@@ -571,7 +571,8 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
 }
 
 
-int forward_batches(lm_engine* e, int slot, const float* x, int n, int H, int W, int batch, uint8_t* labels) {
+int forward_batches(lm_engine* e, int slot, const float* x, int n, int H, int W, int batch, uint8_t* labels, int gate_slice,
+                    const std::function<int(hipEvent_t*)>& gate) {
     if (batch <= 0) batch = 20;
     const size_t px = (size_t)H * W;
     const bool dual = e->n_streams > 1 && e->stream2 != nullptr && n > batch;
@@ -582,11 +583,24 @@ int forward_batches(lm_engine* e, int slot, const float* x, int n, int H, int W,
     // With two lanes and an odd number of batches the last batch would run alone (at the single-lane rate): it is cut in
     // two halves, one per lane.  (Results do not depend on how slices are batched: every slice is computed on its own.)
     const int n_batches = (n + batch - 1) / batch;
+    bool gate_called = false, gated[2] = {false, false};
+    hipEvent_t gate_ev = nullptr;
     int k = 0;
     for (int b0 = 0; b0 < n; ++k) {
         int b = std::min(batch, n - b0);
         if (dual && (n_batches & 1) && b0 + b >= n && k == n_batches - 1 && b >= 2) b = (b + 1) / 2;
-        LM_TRY(forward(e, slot, x + (size_t)b0 * px, b, H, W, labels + (size_t)b0 * px, nullptr, dual ? (k & 1) : 0));
+        const int lane = dual ? (k & 1) : 0;
+        if (gate && gate_slice >= 0 && b0 + b > gate_slice) {  // this batch touches the gated part of the volume
+            if (!gate_called) {
+                gate_called = true;
+                LM_TRY(gate(&gate_ev));
+            }
+            if (gate_ev != nullptr && !gated[lane]) {
+                gated[lane] = true;
+                LM_HIP(hipStreamWaitEvent(lane ? e->stream2 : e->stream, gate_ev, 0));
+            }
+        }
+        LM_TRY(forward(e, slot, x + (size_t)b0 * px, b, H, W, labels + (size_t)b0 * px, nullptr, lane));
         b0 += b;
     }
     if (dual) {

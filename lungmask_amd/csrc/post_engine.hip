@@ -36,8 +36,11 @@ namespace {
 
 struct ProfScope {
     lm_engine* e;
-    ProfScope(lm_engine* e_, const char* name, double bytes) : e(e_) { e->prof.begin(e->stream, e->prof.kind_id(name), 0, bytes); }
-    ~ProfScope() { e->prof.end(e->stream); }
+    hipStream_t st;
+    ProfScope(lm_engine* e_, const char* name, double bytes, hipStream_t st_ = nullptr) : e(e_), st(st_ ? st_ : e_->stream) {
+        e->prof.begin(st, e->prof.kind_id(name), 0, bytes);
+    }
+    ~ProfScope() { e->prof.end(st); }
 };
 
 }  // namespace
@@ -344,40 +347,64 @@ int inference(lm_engine* e, int slot, const void* vol, int dtype, int n, int h, 
     LM_TRY(a.xf.reserve((size_t)n * R * R * 4));
     LM_TRY(a.bbox.reserve((size_t)n * 16));
     LM_TRY(a.labels.reserve((size_t)n * R * R));
-    // Slices are independent up to the argmax (mask.py:166-187), so the volume is worked on in up to two pieces: when
-    // lm_apply_host is still copying the tail of the volume in (engine.h: head_slices / tail_ready), the head's pre-processing
-    // and forward run meanwhile.
+    // Slices are independent up to the argmax (mask.py:166-187), so the volume is pre-processed in two pieces: the head (the
+    // first batch of each forward lane) on the main stream, the tail on the copy stream while the head runs through the network
+    // -- behind lm_apply_host's copy of the tail when the volume is still arriving (engine.h: head_slices / tail_ready).  The
+    // batch loop is ONE loop over the whole volume: the lanes wait for the tail's pre-processing where they first need it, they
+    // are never joined in between (round 2 ran head and tail as two loops: a drain of both lanes and a second body-mask latency).
     const int esz = dtype == LM_I16 ? 2 : ((dtype == LM_I32 || dtype == LM_F32) ? 4 : 8);
-    const int head = (e->head_slices > 0 && e->head_slices < n) ? e->head_slices : n;
+    const bool arriving = e->head_slices > 0 && e->head_slices < n;  // lm_apply_host is copying slices >= head_slices in
+    const int lanes = (e->n_streams > 1 && e->stream2 != nullptr) ? 2 : 1;
+    int head = arriving ? e->head_slices : (n > 2 * lanes * batch ? lanes * batch : n);
+    if (have_pre) head = n;
     // (a flag left behind by a forward that was never checked must not be attributed to this model)
     if (e->range_flag != nullptr) LM_HIP(hipMemsetAsync(e->range_flag, 0, sizeof(unsigned), e->stream));
-    for (int s0 = 0; s0 < n; s0 += (s0 == 0 ? head : n)) {
-        const int ns = s0 == 0 ? head : n - s0;
-        if (s0 > 0) {
-            while (e->tail_enqueued.load(std::memory_order_acquire) == 0) std::this_thread::yield();  // normally long done: the head took milliseconds
+    auto preprocess = [&](int s0, int ns, hipStream_t st) -> int {  // mask.py:166-168
+        const char* v = reinterpret_cast<const char*>(vol) + (size_t)s0 * h * w * esz;
+        BodyMaskParams bp{v, dtype, ns, h, w, a.bbox.as<int>() + (size_t)s0 * 4, nullptr};
+        {
+            ProfScope ps(e, "bodymask_bbox", (double)ns * 128 * 128 * esz, st);
+            LM_K(launch_bodymask_bbox(bp, st));
+        }
+        ResampleParams rp{v, dtype, ns, h, w, a.bbox.as<int>() + (size_t)s0 * 4, R, R, nullptr, a.xf.as<float>() + (size_t)s0 * R * R};
+        {
+            ProfScope ps(e, "resample_norm", (double)ns * h * w * esz + (double)ns * R * R * 4, st);
+            LM_K(launch_resample_norm(rp, st));
+        }
+        return LM_OK;
+    };
+    if (head < n && !e->copy_stream) {
+        if (hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->tail_ready, hipEventDisableTiming) != hipSuccess) {
+            set_error("creating the copy stream failed");
+            return LM_ERR_DEVICE;
+        }
+    }
+    if (head < n && !e->pre_fork) {
+        if (hipEventCreateWithFlags(&e->pre_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->pre_tail_done, hipEventDisableTiming) != hipSuccess) {
+            set_error("creating the pre-processing events failed");
+            return LM_ERR_DEVICE;
+        }
+    }
+    if (head < n) LM_HIP(hipEventRecord(e->pre_fork, e->stream));  // everything the caller / the previous volume enqueued
+    if (!have_pre) LM_TRY(preprocess(0, head, e->stream));
+    auto gate = [&](hipEvent_t* ev) -> int {
+        if (arriving) {
+            while (e->tail_enqueued.load(std::memory_order_acquire) == 0) std::this_thread::yield();  // normally long done
             if (e->tail_enqueued.load(std::memory_order_acquire) < 0) {
                 set_error("lm_apply_host: copying the volume to the device failed");
                 return LM_ERR_DEVICE;
             }
-            LM_HIP(hipStreamWaitEvent(e->stream, e->tail_ready, 0));
         }
-        if (!have_pre) {  // mask.py:166-168
-            const char* v = reinterpret_cast<const char*>(vol) + (size_t)s0 * h * w * esz;
-            BodyMaskParams bp{v, dtype, ns, h, w, a.bbox.as<int>() + (size_t)s0 * 4, nullptr};
-            {
-                ProfScope ps(e, "bodymask_bbox", (double)ns * 128 * 128 * esz);
-                LM_K(launch_bodymask_bbox(bp, e->stream));
-            }
-            ResampleParams rp{v, dtype, ns, h, w, a.bbox.as<int>() + (size_t)s0 * 4, R, R, nullptr, a.xf.as<float>() + (size_t)s0 * R * R};
-            {
-                ProfScope ps(e, "resample_norm", (double)ns * h * w * esz + (double)ns * R * R * 4);
-                LM_K(launch_resample_norm(rp, e->stream));
-            }
-        }
-        // mask.py:173-187.  The f16 range flag is read back ONCE, behind the last piece: a check per piece would make the host wait
-        // for the head's forward before it could enqueue the tail's
-        LM_TRY(forward_batches(e, slot, a.xf.as<float>() + (size_t)s0 * R * R, ns, R, R, batch, a.labels.as<uint8_t>() + (size_t)s0 * R * R));
-    }
+        // (the copy stream already holds lm_apply_host's copy of the tail, if any: stream order)
+        LM_HIP(hipStreamWaitEvent(e->copy_stream, e->pre_fork, 0));
+        LM_TRY(preprocess(head, n - head, e->copy_stream));
+        LM_HIP(hipEventRecord(e->pre_tail_done, e->copy_stream));
+        *ev = e->pre_tail_done;
+        return LM_OK;
+    };
+    // mask.py:173-187
+    if (head < n) LM_TRY(forward_batches(e, slot, a.xf.as<float>(), n, R, R, batch, a.labels.as<uint8_t>(), head, gate));
+    else LM_TRY(forward_batches(e, slot, a.xf.as<float>(), n, R, R, batch, a.labels.as<uint8_t>()));
     // The f16 range flag of the forward passes is read back once per volume: inside the post-processing's first round trip when
     // there is one, on its own otherwise.  When it is set the model is now pinned to the exact-fp32 kernels: the whole volume
     // again (its pre-processed slices are all there).
