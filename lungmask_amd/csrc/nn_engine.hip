@@ -494,34 +494,24 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
 #else
     const int abl = 0;
 #endif
-    // The full-resolution level's tensors are 16 MiB per slice: a 20-slice batch writes 336 MB per layer, more than the 256 MB
-    // memory-side cache, so the producer -> consumer pairs of that level (first conv -> conv 2; upsample -> conv -> conv + head)
-    // can be run in sub-batches of LM_L0_SUB slices each (0 = whole batch).  Results do not depend on it.
-    static const int l0_sub_env = [] { const char* v = getenv("LM_L0_SUB"); return v ? atoi(v) : 0; }();
-    const int l0_sub = (l0_sub_env > 0 && l0_sub_env < B) ? l0_sub_env : B;
-    const size_t px1 = (size_t)H * W;  // pixels of one slice at full resolution
+    // (Running the full-resolution level in sub-batches of 10 / 5 / 4 slices so that its producer -> consumer pairs stay inside the
+    // 256 MB memory-side cache was measured in round 3 and gains nothing -- profiles/r03k_l0_subbatch.log: written data does not
+    // stay there.)
     // ---- encoder (resunet.py:60-64)
-    for (int s0 = 0; s0 < B; s0 += l0_sub) {
-        const int nb = std::min(l0_sub, B - s0);
-        Fwd fs = f;
-        fs.B = nb;
-        if (!(abl & 1)) {
-            FirstConvParams p{x + s0 * px1, md.first.w, md.first.bias, md.first.bn_s, f.defer ? md.zeros_h3 : md.first.bn_t, t1 + s0 * px1 * 64, 64, 0, nb, H, W, h3 ? e->range_flag : nullptr};
-            e->prof.begin(stream, f.kfirst, 2.0 * nb * px1 * 64 * 9, 4.0 * nb * px1 * 65);
-            hipError_t err = h3 ? launch_first_conv_h3(p, stream) : launch_first_conv(p, stream);
-            e->prof.end(stream);
-            if (err != hipSuccess) {
-                set_error("first_conv launch failed: %s", hipGetErrorString(err));
-                return LM_ERR_DEVICE;
-            }
+    if (!(abl & 1)) {
+        FirstConvParams p{x, md.first.w, md.first.bias, md.first.bn_s, f.defer ? md.zeros_h3 : md.first.bn_t, t1, 64, 0, B, H, W, h3 ? e->range_flag : nullptr};
+        e->prof.begin(stream, f.kfirst, 2.0 * px * 64 * 9, 4.0 * px * 65);
+        hipError_t err = h3 ? launch_first_conv_h3(p, stream) : launch_first_conv(p, stream);
+        e->prof.end(stream);
+        if (err != hipSuccess) {
+            set_error("first_conv launch failed: %s", hipGetErrorString(err));
+            return LM_ERR_DEVICE;
         }
-        // skip tensor goes straight into the second half of the level's concat buffer, pooled copy alongside
-        LM_TRY(fs.conv(md.down[0][1], t1 + s0 * px1 * 64, 64, 0, H, W, ws.cat[0].as<float>() + s0 * px1 * 128, 128, 64, ws.pool[0].as<float>() + s0 * (px1 / 4) * 64, 64, 0));
     }
-    for (int i = 1; i < 5; ++i) {
+    for (int i = 0; i < 5; ++i) {
         const int h = H >> i, w = W >> i, c = 64 << i;
-        LM_TRY(f.conv(md.down[i][0], ws.pool[i - 1].as<float>(), c / 2, 0, h, w, t1, c, 0));
-        if (i < 4)
+        if (i > 0) LM_TRY(f.conv(md.down[i][0], ws.pool[i - 1].as<float>(), c / 2, 0, h, w, t1, c, 0));
+        if (i < 4)  // skip tensor goes straight into the second half of the level's concat buffer, pooled copy alongside
             LM_TRY(f.conv(md.down[i][1], t1, c, 0, h, w, ws.cat[i].as<float>(), 2 * c, c, ws.pool[i].as<float>(), c, 0));
         else
             LM_TRY(f.conv(md.down[i][1], t1, c, 0, h, w, t3, c, 0));
@@ -532,29 +522,21 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
         const int lvl = 3 - i;
         const int h = H >> lvl, w = W >> lvl, c = 64 << lvl;
         LM_TRY(f.conv(md.up1x1[i], t3, 2 * c, 0, h / 2, w / 2, t2, c, 0));
-        const int sub = lvl == 0 ? l0_sub : B;
-        for (int s0 = 0; s0 < B; s0 += sub) {
-            const int nb = std::min(sub, B - s0);
-            Fwd fs = f;
-            fs.B = nb;
-            const size_t opx = (size_t)h * w;  // pixels of one slice at this level
-            if (!(abl & 4)) {
-                UpsampleParams p{t2 + s0 * (opx / 4) * c, ws.cat[lvl].as<float>() + s0 * opx * 2 * c, 2 * c, 0, nb, h / 2, w / 2, c};
-                e->prof.begin(stream, f.kup, 0, 4.0 * ((double)nb * opx * c + (double)nb * opx / 4 * c));
-                hipError_t err = h3 ? launch_upsample2x_h3(p, stream) : launch_upsample2x(p, stream);
-                e->prof.end(stream);
-                if (err != hipSuccess) {
-                    set_error("upsample launch failed: %s", hipGetErrorString(err));
-                    return LM_ERR_DEVICE;
-                }
+        if (!(abl & 4)) {
+            UpsampleParams p{t2, ws.cat[lvl].as<float>(), 2 * c, 0, B, h / 2, w / 2, c};
+            const double opx = (double)B * h * w;
+            e->prof.begin(stream, f.kup, 0, 4.0 * (opx * c + opx / 4 * c));
+            hipError_t err = h3 ? launch_upsample2x_h3(p, stream) : launch_upsample2x(p, stream);
+            e->prof.end(stream);
+            if (err != hipSuccess) {
+                set_error("upsample launch failed: %s", hipGetErrorString(err));
+                return LM_ERR_DEVICE;
             }
-            LM_TRY(fs.conv(md.upc[i][0], ws.cat[lvl].as<float>() + s0 * opx * 2 * c, 2 * c, 0, h, w, t1 + s0 * opx * c, c, 0));
-            // the last conv takes the head (1x1 conv + argmax) into its epilogue when only labels are wanted
-            const HeadParams hp{t3 + s0 * opx * c, md.head_w, f.defer ? md.head_b_h3 : md.head_b, labels ? labels + s0 * px1 : nullptr,
-                                logp ? logp + s0 * px1 * md.n_classes : nullptr, nb, H, W, md.n_classes};
-            LM_TRY(fs.conv(md.upc[i][1], t1 + s0 * opx * c, c, 0, h, w, t3 + s0 * opx * c, c, 0, nullptr, 0, 0, i == 3 ? &hp : nullptr));
-            if (fs.head_fused) f.head_fused = true;
         }
+        LM_TRY(f.conv(md.upc[i][0], ws.cat[lvl].as<float>(), 2 * c, 0, h, w, t1, c, 0));
+        // the last conv takes the head (1x1 conv + argmax) into its epilogue when only labels are wanted
+        const HeadParams hp{t3, md.head_w, f.defer ? md.head_b_h3 : md.head_b, labels, logp, B, H, W, md.n_classes};
+        LM_TRY(f.conv(md.upc[i][1], t1, c, 0, h, w, t3, c, 0, nullptr, 0, 0, i == 3 ? &hp : nullptr));
     }
     // ---- head (resunet.py:69-70, mask.py:184-186)
     if (!f.head_fused) {
