@@ -39,11 +39,7 @@ def test_world_size_must_match_gpus():
     assert r.returncode != 0 and "--gpus 1 but WORLD_SIZE=2" in r.stderr
 
 
-def test_self_spawned_two_ranks_over_gloo_and_the_emulator():
-    from lungmask_amd.build import build_emu
-
-    build_emu()  # once, before two ranks race to build it
-    r = _run(["--gpus", "2", "--slices", "3", "--steps", "1", "--warmup", "0", "--batch", "2", "--no-cpu-baseline"], {"LM_BENCH_EMU": "1"})
+def _check_line(r, n_local):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout  # rank 0 only
@@ -51,5 +47,33 @@ def test_self_spawned_two_ranks_over_gloo_and_the_emulator():
     assert out["n_gpus"] == 2 and out["collective_world"] == 2 and out["collectives"].startswith("torch.distributed/gloo")
     assert out["steps"] == 1 and out["scaling"] == "weak" and out["value"] > 0
     assert "EMULATION TEST HOOK" in out["data"]
-    assert "96x80x3 int16 HU phantom per GPU (6 slices total)" in out["config"]["workload"]
+    assert f"96x80x{n_local} int16 HU phantom per GPU ({2 * n_local} slices total)" in out["config"]["workload"]
     assert "cpu_baseline" not in out
+
+
+def test_self_spawned_two_ranks_over_gloo_and_the_emulator():
+    from lungmask_amd.build import build_emu
+
+    build_emu()  # once, before two ranks race to build it
+    r = _run(["--gpus", "2", "--slices", "2", "--steps", "1", "--warmup", "0", "--batch", "2", "--no-cpu-baseline"], {"LM_BENCH_EMU": "1"})
+    _check_line(r, 2)
+
+
+def test_two_ranks_under_torch_distributed_run():
+    """The way the driver launches N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher's environment)."""
+    import socket
+
+    from lungmask_amd.build import build_emu
+
+    build_emu()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(LM_BENCH_EMU="1", OMP_NUM_THREADS="4")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), BENCH, "--gpus", "2", "--slices", "1", "--steps", "1", "--warmup", "0", "--batch", "2",
+                        "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    _check_line(r, 1)
