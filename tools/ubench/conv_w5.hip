@@ -1,4 +1,11 @@
-// LAB (not part of the product): the persistent 3x3 conv with ONE wave per SIMD -- 256 threads, wave w owns FOUR rows of the
+// LAB (not part of the product): conv_w5's main loop (one wave per SIMD, 4 rows per wave) with the EPILOGUE OF ITEM i RUNNING
+// INSIDE THE MAIN LOOP OF ITEM i + 1: a second accumulator set (the lone wave may use 512 registers), the epilogue cut into 32
+// units of one (channel group, row) each -- bias / ReLU / BatchNorm / split, a v_permlane32_swap exchange so that every lane holds
+// 16 contiguous bytes, one store straight from registers (no LDS staging, no fences) -- and one unit issued behind every eighth
+// matrix instruction of the next item's first two chunks.
+// (conv_w5.hip is the same kernel with the epilogue in its usual place.)
+// --- original header of conv_w5.hip:
+// the persistent 3x3 conv with ONE wave per SIMD -- 256 threads, wave w owns FOUR rows of the
 // 16 x 32 tile (2 M-tiles x 4 N-tiles = 128 accumulator registers of the 512 a lone wave may use).  Question asked: does the
 // main loop get cheaper when a wave's weight fragments serve four rows instead of two and its activation fragments are reused
 // across the three vertical taps (per chunk 72 + 36 = 108 fragment reads per SIMD instead of 144), without a partner wave to
@@ -6,7 +13,7 @@
 // column-major (dx outer) so that the six halo rows of one column offset stay in registers for three taps -- the fp32 summation
 // order differs from the product kernel, outputs are compared with a tolerance.
 //
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I lungmask_amd/csrc -I include tools/ubench/conv_w4.hip -o tools/ubench/conv_w4
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I lungmask_amd/csrc -I include tools/ubench/conv_w5.hip -o tools/ubench/conv_w5
 #include "../../lungmask_amd/csrc/nn_kernels_h3.hip"
 
 #include <cmath>
@@ -18,8 +25,8 @@ namespace lm {
 
 // DIRECT: the epilogue stores straight from registers -- a lane pair (kb = 0 / 1 of one pixel) exchanges halves with
 // v_permlane32_swap so that each lane holds 16 contiguous bytes (hi8 / lo8 of an 8-channel group) -- instead of through LDS staging
-template <bool POOLT, bool DIRECT>
-__global__ __launch_bounds__(256) void conv_igemm_w4(ConvParamsH3 p, int n_ptiles, int n_items, int xcd_order) {
+template <bool POOLT>
+__global__ __launch_bounds__(256) void conv_igemm_w5(ConvParamsH3 p, int n_ptiles, int n_items, int xcd_order) {
     using SM = H3WSmem<9, false>;
     constexpr int PW = SM::PW, ROWB = PW * 64, NWV = 4;
     constexpr int A_PER_WAVE = (SM::A_PIECES + NWV - 1) / NWV, W_PER_WAVE = (SM::W_PIECES + NWV - 1) / NWV;
@@ -133,7 +140,72 @@ __global__ __launch_bounds__(256) void conv_igemm_w4(ConvParamsH3 p, int n_ptile
         }
     };
 
-    lm_f32x16 acc[2][4];
+    lm_f32x16 acc[2][4], accO[2][4];
+    int o_b = 0, o_y0 = 0, o_x0 = 0, o_n0 = 0, o_epar = 0;
+    bool pending = false;
+    float4 u_bias, u_s, u_sh;  // constants of the running (M-tile, channel group): loaded by its first unit, used by four
+    float u_prev[4];           // the previous row's values of the group (2x2 average pool)
+    const int Hp = p.H >> 1, Wp = p.W >> 1;
+    // unit U = 16 * mt + 4 * g4 + nt of the deferred epilogue: one 4-channel group of one row of this wave
+#define W5_EPI_UNIT(U)                                                                                                      \
+    do {                                                                                                                   \
+        if ((U) >= 0 && (U) < 32) {                                                                                        \
+            constexpr int u_ = (U) >= 0 && (U) < 32 ? (U) : 0;                                                              \
+            constexpr int mt_ = (u_ >> 4) & 1, g4_ = (u_ >> 2) & 3, nt_ = u_ & 3;                                           \
+            const int cl_ = 32 * mt_ + 8 * g4_ + 4 * kb;                                                                   \
+            if (nt_ == 0) {                                                                                                \
+                const char* ep_ = reinterpret_cast<const char*>(&epi[o_epar][0][0]);                                       \
+                u_bias = *reinterpret_cast<const float4*>(ep_ + cl_ * 4);                                                  \
+                u_s = *reinterpret_cast<const float4*>(ep_ + TN * 4 + cl_ * 4);                                            \
+                u_sh = *reinterpret_cast<const float4*>(ep_ + 2 * TN * 4 + cl_ * 4);                                       \
+            }                                                                                                              \
+            const int yl_ = o_y0 + wrow + nt_, xl_ = o_x0 + li;                                                            \
+            float bb_[4] = {u_bias.x, u_bias.y, u_bias.z, u_bias.w};                                                       \
+            if (p.border_corr != nullptr) {                                                                                \
+                const int bm_ = (yl_ == 0 ? 1 : 0) | (yl_ == p.H - 1 ? 2 : 0) | (xl_ == 0 ? 4 : 0) | (xl_ == p.W - 1 ? 8 : 0); \
+                if (__any(bm_ != 0)) {                                                                                     \
+                    const float4 c_ = *reinterpret_cast<const float4*>(p.border_corr + (size_t)bm_ * p.Cout + o_n0 + cl_); \
+                    bb_[0] -= c_.x; bb_[1] -= c_.y; bb_[2] -= c_.z; bb_[3] -= c_.w;                                        \
+                }                                                                                                          \
+            }                                                                                                              \
+            const float ss_[4] = {u_s.x, u_s.y, u_s.z, u_s.w}, tt_[4] = {u_sh.x, u_sh.y, u_sh.z, u_sh.w};                   \
+            float v_[4];                                                                                                   \
+            _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                                \
+                const float t_ = fmaf(accO[mt_][nt_][4 * g4_ + k], p.acc_scale, bb_[k]);                                   \
+                v_[k] = fmaf(fmaxf(t_, 0.f), ss_[k], tt_[k]);                                                              \
+            }                                                                                                              \
+            uint2 ph_, plo_;                                                                                               \
+            lm_split4(v_[0], v_[1], v_[2], v_[3], &ph_, &plo_);                                                            \
+            {                                                                                                              \
+                const auto r0_ = __builtin_amdgcn_permlane32_swap(ph_.x, plo_.x, false, false);                            \
+                const auto r1_ = __builtin_amdgcn_permlane32_swap(ph_.y, plo_.y, false, false);                            \
+                const uint4 val_ = {(unsigned)r0_[0], (unsigned)r1_[0], (unsigned)r0_[1], (unsigned)r1_[1]};               \
+                if (o_b < p.B && yl_ < p.H) {                                                                              \
+                    char* dst_ = p.out + ((((size_t)o_b * p.H + yl_) * p.W + xl_) * p.out_cstride + p.out_coff + o_n0) * 4 + (4 * mt_ + g4_) * 32 + kb * 16; \
+                    *reinterpret_cast<uint4*>(dst_) = val_;                                                                \
+                }                                                                                                          \
+            }                                                                                                              \
+            if (POOLT) {                                                                                                   \
+                if ((nt_ & 1) == 0) {                                                                                      \
+                    _Pragma("unroll") for (int k = 0; k < 4; ++k) u_prev[k] = v_[k];                                       \
+                } else {                                                                                                   \
+                    float q_[4];                                                                                           \
+                    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                        \
+                        const float pl_ = u_prev[k] + v_[k];                                                               \
+                        q_[k] = 0.25f * (pl_ + lm_lane_xor1(pl_));                                                         \
+                    }                                                                                                      \
+                    lm_split4(q_[0], q_[1], q_[2], q_[3], &ph_, &plo_);                                                    \
+                    const auto r0_ = __builtin_amdgcn_permlane32_swap(ph_.x, plo_.x, false, false);                        \
+                    const auto r1_ = __builtin_amdgcn_permlane32_swap(ph_.y, plo_.y, false, false);                        \
+                    const uint4 val_ = {(unsigned)r0_[0], (unsigned)r1_[0], (unsigned)r0_[1], (unsigned)r1_[1]};           \
+                    if ((li & 1) == 0 && o_b < p.B && yl_ < p.H) {                                                         \
+                        char* pd_ = p.pool + ((((size_t)o_b * Hp + (yl_ >> 1)) * Wp + (xl_ >> 1)) * p.pool_cstride + p.pool_coff + o_n0) * 4 + (4 * mt_ + g4_) * 32 + kb * 16; \
+                        *reinterpret_cast<uint4*>(pd_) = val_;                                                             \
+                    }                                                                                                      \
+                }                                                                                                          \
+            }                                                                                                              \
+        }                                                                                                                  \
+    } while (0)
     int it = blockIdx.x;
     int b, y0, x0, n0;
     while (it < n_items && !decode(it, b, y0, x0, n0)) it += gridDim.x;
@@ -173,17 +245,28 @@ __global__ __launch_bounds__(256) void conv_igemm_w4(ConvParamsH3 p, int n_ptile
         __builtin_amdgcn_sched_barrier(0);                                                                                 \
     } while (0)
     // 24 matrix instructions of tap (DY, column set SA, weight set SW), K0 = first of three DMA slots spread over them (or -1)
-#define W4_MFMAS(SA, SW, DY, K0)                                                                                            \
+#define W4_GROUP(SA, SW, DY, PR)                                                                                            \
     do {                                                                                                                   \
-        _Pragma("unroll") for (int pr = 0; pr < 3; ++pr) {                                                                 \
-            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) {                                                             \
-                _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                         \
-                    acc[mt][nt] = lm_mfma_f32_32x32x16_f16(fw[SW][(pr == 2 ? 2 : 0) + mt], fa[SA][2 * ((DY) + nt) + (pr == 1 ? 1 : 0)], acc[mt][nt]); \
-                }                                                                                                          \
+        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) {                                                                 \
+            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                             \
+                acc[mt][nt] = lm_mfma_f32_32x32x16_f16(fw[SW][((PR) == 2 ? 2 : 0) + mt], fa[SA][2 * ((DY) + nt) + ((PR) == 1 ? 1 : 0)], acc[mt][nt]); \
             }                                                                                                              \
-            if ((K0) >= 0) dma_slot((K0) + pr);                                                                            \
         }                                                                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    } while (0)
+#define W4_SLOT(K, E)                                              \
+    do {                                                           \
+        if ((K) >= 0) dma_slot(K);                                 \
+        if ((E) >= 0 && pending) { W5_EPI_UNIT(E); }               \
+    } while (0)
+#define W4_MFMAS(SA, SW, DY, K0, E0)                               \
+    do {                                                           \
+        W4_GROUP(SA, SW, DY, 0);                                   \
+        W4_SLOT((K0) >= 0 ? (K0) : -1, (E0) >= 0 ? (E0) : -1);     \
+        W4_GROUP(SA, SW, DY, 1);                                   \
+        W4_SLOT((K0) >= 0 ? (K0) + 1 : -1, (E0) >= 0 ? (E0) + 1 : -1); \
+        W4_GROUP(SA, SW, DY, 2);                                   \
+        W4_SLOT((K0) >= 0 ? (K0) + 2 : -1, (E0) >= 0 ? (E0) + 2 : -1); \
+        __builtin_amdgcn_sched_barrier(0);                         \
     } while (0)
 
     while (true) {
@@ -204,7 +287,7 @@ __global__ __launch_bounds__(256) void conv_igemm_w4(ConvParamsH3 p, int n_ptile
         // Register-set parities: a chunk has 9 taps and 3 column groups, both odd, so the weight set of (chunk c, tap t) is
         // (c + t) & 1 and the activation set of (chunk c, column dx) is (c + dx) & 1 -- the set a prefetch writes is never the one
         // the running matrix instructions read.  Chunks are unrolled in pairs (the chunk count is even) to keep every index static.
-#define W4_TAP(PAR, T, AS, AN, LAST)                                                                                        \
+#define W4_TAP(PAR, T, AS, AN, LAST, EPI)                                                                                       \
     do {                                                                                                                   \
         constexpr int dxi_ = (T) / 3, dyi_ = (T) - 3 * dxi_;                                                               \
         W4_WAIT_ALL(); /* every read issued during the previous tap has landed (it had 768 cycles) */                     \
@@ -220,165 +303,48 @@ __global__ __launch_bounds__(256) void conv_igemm_w4(ConvParamsH3 p, int n_ptile
             constexpr int tn_ = (T) + 1, ndx_ = tn_ / 3, ndy_ = tn_ - 3 * ndx_;                                            \
             W4_READS_W(((PAR) + tn_) & 1, AS, 3 * ndy_ + ndx_);                                                            \
         }                                                                                                                  \
-        W4_MFMAS(((PAR) + dxi_) & 1, ((PAR) + (T)) & 1, dyi_, (T) < 7 ? 3 * (T) : -1);                                     \
+        W4_MFMAS(((PAR) + dxi_) & 1, ((PAR) + (T)) & 1, dyi_, (T) < 7 ? 3 * (T) : -1, (EPI) > 0 ? ((EPI) - 1) * 27 + 3 * (T) : -1); \
     } while (0)
-#define W4_CHUNK(PAR, AS, AN, LAST)    \
+#define W4_CHUNK(PAR, AS, AN, LAST, EPI)    \
     do {                               \
-        W4_TAP(PAR, 0, AS, AN, LAST);  \
-        W4_TAP(PAR, 1, AS, AN, LAST);  \
-        W4_TAP(PAR, 2, AS, AN, LAST);  \
-        W4_TAP(PAR, 3, AS, AN, LAST);  \
-        W4_TAP(PAR, 4, AS, AN, LAST);  \
-        W4_TAP(PAR, 5, AS, AN, LAST);  \
-        W4_TAP(PAR, 6, AS, AN, LAST);  \
-        W4_TAP(PAR, 7, AS, AN, LAST);  \
-        W4_TAP(PAR, 8, AS, AN, LAST);  \
+        W4_TAP(PAR, 0, AS, AN, LAST, EPI);  \
+        W4_TAP(PAR, 1, AS, AN, LAST, EPI);  \
+        W4_TAP(PAR, 2, AS, AN, LAST, EPI);  \
+        W4_TAP(PAR, 3, AS, AN, LAST, EPI);  \
+        W4_TAP(PAR, 4, AS, AN, LAST, EPI);  \
+        W4_TAP(PAR, 5, AS, AN, LAST, EPI);  \
+        W4_TAP(PAR, 6, AS, AN, LAST, EPI);  \
+        W4_TAP(PAR, 7, AS, AN, LAST, EPI);  \
+        W4_TAP(PAR, 8, AS, AN, LAST, EPI);  \
     } while (0)
-        for (int ci = 0; ci < nchunks; ci += 2) {
-            // during chunk c (buffer c & 1) the slots of taps 0..6 stage chunk c + 1 into the other buffer: everyone finished
-            // reading it at the barrier that ended chunk c - 1
+        {   // first pair of chunks: carries the units of the PREVIOUS item's epilogue (54 slots for 32 units)
+            set_dma(false, b, n0, KC, 1, true, -1);
+            W4_CHUNK(0, buf0, buf1, false, 1);
+            const bool last = 2 >= nchunks;
+            if (!last) set_dma(false, b, n0, 2 * KC, 0, true, -1);
+            else set_dma(true, nb, nn0, 0, 0, have_next, epar ^ 1);
+            W4_CHUNK(1, buf1, buf0, last, 2);
+        }
+        for (int ci = 2; ci < nchunks; ci += 2) {
             set_dma(false, b, n0, (ci + 1) * KC, 1, true, -1);
-            W4_CHUNK(0, buf0, buf1, false);
+            W4_CHUNK(0, buf0, buf1, false, 0);
             const bool last = ci + 2 >= nchunks;
             if (!last) set_dma(false, b, n0, (ci + 2) * KC, 0, true, -1);
             else set_dma(true, nb, nn0, 0, 0, have_next, epar ^ 1);  // the next item's chunk 0 + epilogue constants
-            W4_CHUNK(1, buf1, buf0, last);
+            W4_CHUNK(1, buf1, buf0, last, 0);
         }
-        // ---- epilogue (the next item's chunk 0 is resident in buffer 0; buffer 1 is the staging area)
-        if (p.head_C == 77) {  // lab: no epilogue at all (one dummy store keeps the accumulators alive): the main loop's own time
-            float sacc = 0.f;
+        // ---- this item's epilogue is DEFERRED: its accumulators move to the second set, its units run inside the next item's
+        // first two chunks (or right here when there is no next item)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
-            if (sacc == 12345.678f) reinterpret_cast<float*>(p.out)[tid] = sacc;
-        } else {
-            char* const hstage = buf1 + wave * (128 * HSTR);
-            const int yb = y0 + wrow;
-            const int Hp = p.H >> 1, Wp = p.W >> 1;
-            const char* ep = reinterpret_cast<const char*>(&epi[epar][0][0]);
-            int bmask4[4];
-            bool border4[4];
-            char* obase[4];
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int yl = yb + nt, xl = x0 + li;
-                bmask4[nt] = (yl == 0 ? 1 : 0) | (yl == p.H - 1 ? 2 : 0) | (xl == 0 ? 4 : 0) | (xl == p.W - 1 ? 8 : 0);
-                border4[nt] = p.border_corr != nullptr && __any(bmask4[nt] != 0);
-                obase[nt] = p.out + ((((size_t)b * p.H + yl) * p.W + x0) * p.out_cstride + p.out_coff + n0) * 4;
-            }
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                float qs[2][4][4];
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int cl = H3P_EPI_CL(4 * mt + g4);
-                    const float4 bias = *reinterpret_cast<const float4*>(ep + cl * 4);
-                    const float4 s = *reinterpret_cast<const float4*>(ep + TN * 4 + cl * 4);
-                    const float4 sh = *reinterpret_cast<const float4*>(ep + 2 * TN * 4 + cl * 4);
-                    const float ss[4] = {s.x, s.y, s.z, s.w}, tt[4] = {sh.x, sh.y, sh.z, sh.w};
-                    float v[4][4];
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) {
-                        float bb[4] = {bias.x, bias.y, bias.z, bias.w};
-                        if (border4[nt]) {
-                            const float4 c = *reinterpret_cast<const float4*>(p.border_corr + (size_t)bmask4[nt] * p.Cout + n0 + cl);
-                            bb[0] -= c.x; bb[1] -= c.y; bb[2] -= c.z; bb[3] -= c.w;
-                        }
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const float t = fmaf(acc[mt][nt][4 * g4 + k], p.acc_scale, bb[k]);
-                            v[nt][k] = fmaf(fmaxf(t, 0.f), ss[k], tt[k]);
-                        }
-                        uint2 ph, plo;
-                        lm_split4(v[nt][0], v[nt][1], v[nt][2], v[nt][3], &ph, &plo);
-                        if (DIRECT) {
-                            const auto r0 = __builtin_amdgcn_permlane32_swap(ph.x, plo.x, false, false);
-                            const auto r1 = __builtin_amdgcn_permlane32_swap(ph.y, plo.y, false, false);
-                            const uint4 val = {(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
-                            if (yb + nt < p.H) {
-                                char* dst = obase[nt] + (size_t)li * p.out_cstride * 4 + (4 * mt + g4) * 32 + kb * 16;
-                                if (p.stream_out) lm_store16_stream(dst, val);
-                                else *reinterpret_cast<uint4*>(dst) = val;
-                            }
-                        } else {
-                        char* d = hstage + (nt * 32 + li) * HSTR + ((cl & 31) >> 3) * 32 + (cl & 7) * 2;
-                        *reinterpret_cast<uint2_a*>(d) = ph;
-                        *reinterpret_cast<uint2_a*>(d + 16) = plo;
-                        }
-                    }
-                    if (POOLT) {
-#pragma unroll
-                        for (int r2 = 0; r2 < 2; ++r2)
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                const float pl = v[2 * r2][k] + v[2 * r2 + 1][k];
-                                qs[r2][g4][k] = 0.25f * (pl + lm_lane_xor1(pl));
-                            }
-                    }
-                }
-                if (DIRECT) {
-                    if (POOLT) {
-#pragma unroll
-                        for (int r2 = 0; r2 < 2; ++r2)
-#pragma unroll
-                            for (int g4 = 0; g4 < 4; ++g4) {
-                                uint2 ph, plo;
-                                lm_split4(qs[r2][g4][0], qs[r2][g4][1], qs[r2][g4][2], qs[r2][g4][3], &ph, &plo);
-                                const auto r0 = __builtin_amdgcn_permlane32_swap(ph.x, plo.x, false, false);
-                                const auto r1 = __builtin_amdgcn_permlane32_swap(ph.y, plo.y, false, false);
-                                const uint4 val = {(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
-                                if ((li & 1) == 0 && yb + 2 * r2 + 1 < p.H) {
-                                    char* prow = p.pool + ((((size_t)b * Hp + ((yb >> 1) + r2)) * Wp + ((x0 + li) >> 1)) * p.pool_cstride + p.pool_coff + n0) * 4;
-                                    *reinterpret_cast<uint4*>(prow + (4 * mt + g4) * 32 + kb * 16) = val;
-                                }
-                            }
-                    }
-                    continue;
-                }
-                lm_wave_lds_fence();
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int q = i * 64 + lane, px = q >> 3, part = q & 7;
-                    if (yb + (i >> 2) < p.H) {
-                        const uint4 val = *reinterpret_cast<const uint4_a*>(hstage + px * HSTR + part * 16);
-                        char* dst = obase[i >> 2] + (size_t)(px & 31) * p.out_cstride * 4 + mt * 128 + part * 16;
-                        if (p.stream_out) lm_store16_stream(dst, val);
-                        else *reinterpret_cast<uint4_a*>(dst) = val;
-                    }
-                }
-                lm_wave_lds_fence();
-                if (POOLT) {
-#pragma unroll
-                    for (int r2 = 0; r2 < 2; ++r2)
-#pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) {
-                            const int cl = H3P_EPI_CL(4 * mt + g4);
-                            uint2 ph, plo;
-                            lm_split4(qs[r2][g4][0], qs[r2][g4][1], qs[r2][g4][2], qs[r2][g4][3], &ph, &plo);
-                            if ((li & 1) == 0) {
-                                char* d = hstage + (r2 * 16 + (li >> 1)) * HSTR + ((cl & 31) >> 3) * 32 + (cl & 7) * 2;
-                                *reinterpret_cast<uint2_a*>(d) = ph;
-                                *reinterpret_cast<uint2_a*>(d + 16) = plo;
-                            }
-                        }
-                    lm_wave_lds_fence();
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int q = i * 64 + lane, px = q >> 3, part = q & 7;  // px 0..31: pooled row px >> 4, pixel px & 15
-                        const int r2 = px >> 4;
-                        if (yb + 2 * r2 + 1 < p.H) {
-                            char* prow = p.pool + ((((size_t)b * Hp + ((yb >> 1) + r2)) * Wp + (x0 >> 1)) * p.pool_cstride + p.pool_coff + n0) * 4;
-                            const uint4 val = *reinterpret_cast<const uint4_a*>(hstage + px * HSTR + part * 16);
-                            *reinterpret_cast<uint4_a*>(prow + (size_t)(px & 15) * p.pool_cstride * 4 + mt * 128 + part * 16) = val;
-                        }
-                    }
-                    lm_wave_lds_fence();
-                }
-            }
-        }
+            for (int j = 0; j < 4; ++j) accO[i][j] = acc[i][j];
+        o_b = b;
+        o_y0 = y0;
+        o_x0 = x0;
+        o_n0 = n0;
+        o_epar = epar;
+        pending = true;
         if (!have_next) break;
         it = nit;
         b = nb;
@@ -388,23 +354,20 @@ __global__ __launch_bounds__(256) void conv_igemm_w4(ConvParamsH3 p, int n_ptile
 #pragma unroll
         for (int j = 0; j < A_PER_WAVE; ++j) voffC[j] = voffN[j];
         epar ^= 1;
-        lm_barrier_lds();
     }
+    // the last item's epilogue, serially
+#define W5_U4(U) W5_EPI_UNIT(U); W5_EPI_UNIT((U) + 1); W5_EPI_UNIT((U) + 2); W5_EPI_UNIT((U) + 3)
+    W5_U4(0); W5_U4(4); W5_U4(8); W5_U4(12); W5_U4(16); W5_U4(20); W5_U4(24); W5_U4(28);
 }
 
-static hipError_t launch_w4(const ConvParamsH3& p, hipStream_t stream, bool direct = false) {
+static hipError_t launch_w5(const ConvParamsH3& p, hipStream_t stream, bool = false) {
     const int n_ptiles = (p.W / 32) * ((p.H + TH - 1) / TH) * p.B;
     const int n_ct = p.Cout / TN;
     const int xcd_order = (n_ct >= 2 && n_ptiles >= 64) ? 1 : 0;
     const int n_items = xcd_order ? 8 * ((n_ptiles + 7) / 8) * n_ct : n_ptiles * n_ct;
     const unsigned blocks = (unsigned)std::min(n_items, 256);
-    if (direct) {
-        if (p.pool) hipLaunchKernelGGL((conv_igemm_w4<true, true>), dim3(blocks), dim3(256), 0, stream, p, n_ptiles, n_items, xcd_order);
-        else hipLaunchKernelGGL((conv_igemm_w4<false, true>), dim3(blocks), dim3(256), 0, stream, p, n_ptiles, n_items, xcd_order);
-    } else {
-        if (p.pool) hipLaunchKernelGGL((conv_igemm_w4<true, false>), dim3(blocks), dim3(256), 0, stream, p, n_ptiles, n_items, xcd_order);
-        else hipLaunchKernelGGL((conv_igemm_w4<false, false>), dim3(blocks), dim3(256), 0, stream, p, n_ptiles, n_items, xcd_order);
-    }
+    if (p.pool) hipLaunchKernelGGL((conv_igemm_w5<true>), dim3(blocks), dim3(256), 0, stream, p, n_ptiles, n_items, xcd_order);
+    else hipLaunchKernelGGL((conv_igemm_w5<false>), dim3(blocks), dim3(256), 0, stream, p, n_ptiles, n_items, xcd_order);
     return hipGetLastError();
 }
 
@@ -484,11 +447,10 @@ int main(int argc, char** argv) {
         p.stream_out = !getenv("W4_NO_NT") && npx * s.Cout * 4.0 > 128.0 * 1048576.0;
         lm::ConvParamsH3 q = p;
         q.out = out2; q.pool = pool2;
-        if (getenv("W4_NO_EPI")) q.head_C = 77;
         CK(hipMemset(out, 0xee, ob)); CK(hipMemset(out2, 0xdd, ob));
         CK(lm::launch_conv3x3_h3(p, 0));
         const bool direct = getenv("W4_DIRECT") != nullptr;
-        CK(lm::launch_w4(q, 0, direct));
+        CK(lm::launch_w5(q, 0, direct));
         CK(hipDeviceSynchronize());
         std::vector<unsigned char> o1(ob), o2(ob), p1(pb), p2(pb);
         CK(hipMemcpy(o1.data(), out, ob, hipMemcpyDeviceToHost));
@@ -497,9 +459,9 @@ int main(int argc, char** argv) {
         const double dmax = max_diff(o1, o2), dpool = pb ? max_diff(p1, p2) : 0.0;
         float ms[2];
         for (int which = 0; which < 2; ++which) {
-            for (int i = 0; i < 2; ++i) CK(which ? lm::launch_w4(q, 0, direct) : lm::launch_conv3x3_h3(p, 0));
+            for (int i = 0; i < 2; ++i) CK(which ? lm::launch_w5(q, 0, direct) : lm::launch_conv3x3_h3(p, 0));
             CK(hipEventRecord(e0));
-            for (int i = 0; i < reps; ++i) CK(which ? lm::launch_w4(q, 0, direct) : lm::launch_conv3x3_h3(p, 0));
+            for (int i = 0; i < reps; ++i) CK(which ? lm::launch_w5(q, 0, direct) : lm::launch_conv3x3_h3(p, 0));
             CK(hipEventRecord(e1));
             CK(hipEventSynchronize(e1));
             CK(hipEventElapsedTime(&ms[which], e0, e1));
