@@ -188,8 +188,11 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
     const bool want_range = range_slot >= 0 && range_tripped != nullptr && e->range_flag != nullptr && e->precision == 1 && !e->models[range_slot].force_f32;
     LM_TRY(ws.h_scalars.reserve(64));
     volatile int* hs = ws.h_scalars.as<int>();  // [0] regions, [1] records
-    int rcap = std::max(16384, ws.last_regions + ws.last_regions / 2 + 1024);
-    unsigned cap = (unsigned)std::min<size_t>(nvox, std::max<size_t>(ws.recs.cap / sizeof(BoundaryRec), 1u << 20));
+    // LM_POST_SMALL_TABLES=1 (test hook): start every table and every read-back guess tiny, so that small test volumes take the
+    // grow-and-repeat and the second-copy paths
+    static const bool tiny = [] { const char* v = getenv("LM_POST_SMALL_TABLES"); return v && v[0] == '1'; }();
+    int rcap = tiny ? 8 : std::max(16384, ws.last_regions + ws.last_regions / 2 + 1024);
+    unsigned cap = tiny ? 8u : (unsigned)std::min<size_t>(nvox, std::max<size_t>(ws.recs.cap / sizeof(BoundaryRec), 1u << 20));
     int R = 0;
     unsigned nrec = 0;
     std::vector<uint8_t> lut(1, 0);
@@ -215,8 +218,8 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
             LM_K(boundary_records(ids, d, ws.recs.as<BoundaryRec>(), count_dev, cap, s));
         }
         // speculative read-back
-        const size_t g_r = (size_t)std::min(rcap, std::max(4096, ws.last_regions + ws.last_regions / 4 + 256));
-        const size_t g_n = std::min<size_t>(cap, std::max<size_t>(32768, (size_t)ws.last_records + ws.last_records / 4 + 1024));
+        const size_t g_r = tiny ? (size_t)std::min(rcap, 4) : (size_t)std::min(rcap, std::max(4096, ws.last_regions + ws.last_regions / 4 + 256));
+        const size_t g_n = tiny ? std::min<size_t>(cap, 4) : std::min<size_t>(cap, std::max<size_t>(32768, (size_t)ws.last_records + ws.last_records / 4 + 1024));
         LM_TRY(ws.h_area.reserve((g_r + 1) * 4));
         LM_TRY(ws.h_labval.reserve(g_r + 1));
         LM_TRY(ws.h_recs.reserve(g_n * sizeof(BoundaryRec)));

@@ -123,3 +123,26 @@ def test_slab_sharded_postprocessing_full_size(gpu_engine):
     finally:
         for e in extra:
             e.close()
+
+
+def test_postprocessing_table_growth_paths_gpu():
+    """As tests/test_prepost_emu.py::test_postprocessing_table_growth_paths_emulated, on the device: LM_POST_SMALL_TABLES=1 makes the
+    speculative region / record tables and read-back guesses tiny, so the golden, random and noise cases take the
+    grow-and-repeat and the second-copy paths (own process: the hook is read once per process)."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import prepost_cases as cases\n"
+            "from lungmask_amd import _native as nat\n"
+            "eng = nat.Engine(0)\n"
+            "assert eng.L.is_gpu and cases.check_postprocess(eng) >= 20\n"
+            "cases.check_postprocess_random(eng, seeds=range(6))\n"
+            "cases.check_postprocess_noise(eng)\n"
+            "cases.check_postprocess_wide_rows(eng)\n"
+            "print('small tables ok', eng.postprocess_info())\n") % (os.path.dirname(here), here)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LM_POST_SMALL_TABLES="1"), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0 and "small tables ok" in r.stdout, r.stdout[-2000:]

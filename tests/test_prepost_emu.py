@@ -61,3 +61,27 @@ def test_slab_sharded_postprocessing_emulated(emu_engine):
     finally:
         for e in extra:
             e.close()
+
+
+def test_postprocessing_table_growth_paths_emulated():
+    """The post-processing sizes its region / record tables from the previous volume and fetches a guessed prefix of them in the
+    same read-back as the counts (post_engine.hip).  With LM_POST_SMALL_TABLES=1 every table and guess starts tiny, so the golden and
+    random cases run through the grow-and-repeat and the second-copy paths -- results must not change.  (Own process: the hook is
+    read once per process.)"""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import prepost_cases as cases\n"
+            "from lungmask_amd import _native as nat\n"
+            "from lungmask_amd.build import build_emu\n"
+            "eng = nat.Engine(0, nat.Library(build_emu(), allow_emulation=True))\n"
+            "assert cases.check_postprocess(eng) >= 20\n"
+            "cases.check_postprocess_random(eng, seeds=range(2))\n"
+            "cases.check_postprocess_noise(eng)\n"
+            "print('small tables ok', eng.postprocess_info())\n") % (os.path.dirname(here), here)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LM_POST_SMALL_TABLES="1", OMP_NUM_THREADS="4"),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0 and "small tables ok" in r.stdout, r.stdout[-2000:]
