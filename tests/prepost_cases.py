@@ -241,3 +241,20 @@ def check_empty_inputs(eng):
     assert eng.reshape_mask(np.zeros((0, 32, 32), np.uint8), np.zeros((0, 4), np.int32), (64, 64)).shape == (0, 64, 64)
     fused, spare = eng.fuse(np.zeros((0, 8, 8), np.uint8), np.zeros((0, 8, 8), np.uint8))
     assert fused.shape == (0, 8, 8) and spare == 1
+
+
+def check_apply_host_failure_leaves_output_untouched(eng):
+    """lm_apply_host faults the caller's output pages in on a helper thread while the network runs; a call that fails (here: an
+    empty model slot, detected after the helper has started) must leave the array exactly as it was, and the engine usable."""
+    from lungmask_amd._native import LMError
+
+    vol = po.phantom(45, 96, 80, seed=3)  # more than two batches of 20: the split (head / tail) path
+    out = np.full(vol.shape, 0xAB, dtype=np.uint8)
+    try:
+        eng.apply(3, vol, out=out)
+    except LMError as ex:
+        assert "slot 3 is empty" in str(ex)
+    else:
+        raise AssertionError("an empty model slot must be an error")
+    assert (out == 0xAB).all()
+    eng.sync()

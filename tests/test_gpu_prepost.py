@@ -146,3 +146,7 @@ def test_postprocessing_table_growth_paths_gpu():
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LM_POST_SMALL_TABLES="1"), stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0 and "small tables ok" in r.stdout, r.stdout[-2000:]
+
+
+def test_apply_host_failure_leaves_output_untouched(gpu_engine):
+    cases.check_apply_host_failure_leaves_output_untouched(gpu_engine)

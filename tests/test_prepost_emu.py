@@ -85,3 +85,7 @@ def test_postprocessing_table_growth_paths_emulated():
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LM_POST_SMALL_TABLES="1", OMP_NUM_THREADS="4"),
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0 and "small tables ok" in r.stdout, r.stdout[-2000:]
+
+
+def test_apply_host_failure_leaves_output_untouched_emulated(emu_engine):
+    cases.check_apply_host_failure_leaves_output_untouched(emu_engine)
