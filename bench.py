@@ -458,8 +458,8 @@ def main():
             "value_lminferer_apply": lmi,
             "roofline": roof,
             "stages_ms_per_step": {s["name"]: round(s["total_ms"], 3) for s in solo},
-            "stages_note": "HIP-event time per kernel kind of ONE step, from the untimed single-lane pass after the timed region (the tail's pre-processing "
-                           "kernels run on the copy stream beside the forward: their event time includes waiting for compute units)",
+            "stages_note": "HIP-event time per kernel kind of ONE step, from the untimed single-lane pass after the timed region (in that pass the whole "
+                           "volume is pre-processed on the main stream; in the timed region the tail's pre-processing runs beside the head's forward)",
             "postprocessing": post_info,
         }
         if world == 1 and not args.no_cpu_baseline and not emu:

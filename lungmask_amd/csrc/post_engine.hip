@@ -360,6 +360,9 @@ int inference(lm_engine* e, int slot, const void* vol, int dtype, int n, int h, 
     const int lanes = (e->n_streams > 1 && e->stream2 != nullptr) ? 2 : 1;
     int head = arriving ? e->head_slices : (n > 2 * lanes * batch ? lanes * batch : n);
     if (have_pre) head = n;
+    // per-kernel profiling pass (lm_profile_enable(e, 1) / 2: HIP events around every launch, bench.py's stage table): everything on
+    // the main stream, so that an event pair measures its kernel and not the wait for compute units beside the forward
+    if (e->prof.on && !e->prof.dominant_only && !arriving) head = n;
     // (a flag left behind by a forward that was never checked must not be attributed to this model)
     if (e->range_flag != nullptr) LM_HIP(hipMemsetAsync(e->range_flag, 0, sizeof(unsigned), e->stream));
     auto preprocess = [&](int s0, int ns, hipStream_t st) -> int {  // mask.py:166-168
