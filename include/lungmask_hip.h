@@ -185,6 +185,11 @@ int lm_apply_host(lm_engine* e, int slot, int fill_slot, const void* vol_host, i
 int lm_forward_batches_dev(lm_engine* e, int slot, const float* x_dev, int n, int h, int w, int batch_size,
                            uint8_t* labels_dev);
 int lm_set_streams(lm_engine* e, int n);
+/* Producer/consumer fusions of the split-f16 forward (default: all on; results are bit-identical either way -- A/B and test hook).
+ * bit 0: down_path.0's first conv (Cin = 1, resunet.py:93-95) computed inside the loader of its second conv;
+ * bit 1: the decoder's bilinear x2 (resunet.py:131-133) computed inside the loader of the block's first conv;
+ * bit 2: fixed-order split-K for the 16 x 16 decoder 1x1 conv. */
+int lm_set_fusion(lm_engine* e, int mask);
 
 /* Per-kernel timing of the launches since the last reset (HIP events on the launching stream).
  * lm_profile_enable(e, on): 0 off; 1 every kernel; 2 every kernel, one entry per conv layer shape;
@@ -200,6 +205,14 @@ typedef struct lm_kernel_stat {
 int lm_profile_enable(lm_engine* e, int on);
 int lm_profile_reset(lm_engine* e);
 int lm_profile_read(lm_engine* e, lm_kernel_stat* out, int cap);
+/* Timeline of the launches since the last reset (lm_profile_enable(e, 4): per-layer names + start/end of every launch in
+ * milliseconds since the first recorded launch, with the forward lane it ran on): what runs beside what when two lanes are on. */
+typedef struct lm_launch_span {
+    char name[48];
+    int lane;
+    double start_ms, end_ms;
+} lm_launch_span;
+int lm_profile_timeline(lm_engine* e, lm_launch_span* out, int cap);
 
 #ifdef __cplusplus
 }

@@ -39,6 +39,10 @@ class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
 
 
+class LaunchSpan(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("lane", C.c_int), ("start_ms", C.c_double), ("end_ms", C.c_double)]
+
+
 class Library:
     def __init__(self, path: Optional[str] = None, allow_emulation: bool = False):
         path = path or os.environ.get("LUNGMASK_HIP_LIB") or DEFAULT_LIB
@@ -77,6 +81,7 @@ class Library:
         L.lm_forward_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.lm_set_precision.argtypes = [C.c_void_p, C.c_int]
         L.lm_set_streams.argtypes = [C.c_void_p, C.c_int]
+        L.lm_set_fusion.argtypes = [C.c_void_p, C.c_int]
         L.lm_forward_batches_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.lm_preprocess_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_int] * 5 + [C.c_void_p] * 4
         L.lm_reshape_mask_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
@@ -95,6 +100,8 @@ class Library:
         L.lm_profile_enable.argtypes = [C.c_void_p, C.c_int]
         L.lm_profile_reset.argtypes = [C.c_void_p]
         L.lm_profile_read.argtypes = [C.c_void_p, C.POINTER(KernelStat), C.c_int]
+        if hasattr(L, "lm_profile_timeline"):
+            L.lm_profile_timeline.argtypes = [C.c_void_p, C.POINTER(LaunchSpan), C.c_int]
         self.is_gpu = bool(L.lm_is_gpu_build())
         if not self.is_gpu and not allow_emulation:
             raise LMError(f"{path} is not a GPU build; refusing to run the product path on an emulation library")
@@ -246,6 +253,11 @@ class Engine:
 
     def set_streams(self, n: int):
         self.L.check(self.L.lib.lm_set_streams(self.h, int(n)), "lm_set_streams")
+
+    def set_fusion(self, mask: int):
+        """Bit 0: first conv inside conv 2's loader; bit 1: bilinear x2 inside the decoder conv's loader; bit 2: split-K 1x1.
+        Default 7; results are bit-identical for every mask (A/B and test hook)."""
+        self.L.check(self.L.lib.lm_set_fusion(self.h, int(mask)), "lm_set_fusion")
 
     def forward_dev(self, slot: int, x: DeviceArray, labels: Optional[DeviceArray] = None, logp: Optional[DeviceArray] = None):
         b, h, w = x.shape
@@ -406,6 +418,12 @@ class Engine:
 
     def profile_reset(self):
         self.L.check(self.L.lib.lm_profile_reset(self.h))
+
+    def profile_timeline(self, cap: int = 4096):
+        """After profile(4): [(name, lane, start_ms, end_ms)] of every launch since the last reset."""
+        buf = (LaunchSpan * cap)()
+        n = self.L.check(self.L.lib.lm_profile_timeline(self.h, buf, cap))
+        return [(buf[i].name.decode(), buf[i].lane, buf[i].start_ms, buf[i].end_ms) for i in range(min(n, cap))]
 
     def profile_read(self):
         buf = (KernelStat * 96)()

@@ -149,6 +149,15 @@ int lm_set_streams(lm_engine* e, int n) {
     return LM_OK;
 }
 
+int lm_set_fusion(lm_engine* e, int mask) {
+    if (!e || mask < 0 || mask > 7) {
+        set_error("lm_set_fusion: mask is a combination of bits 0..2");
+        return LM_ERR_INVALID;
+    }
+    e->fusion = mask;
+    return LM_OK;
+}
+
 int lm_forward_batches_dev(lm_engine* e, int slot, const float* x_dev, int n, int h, int w, int batch_size, uint8_t* labels_dev) {
     if (!e || !x_dev || !labels_dev || n < 0) return LM_ERR_INVALID;
     LM_DEVICE(e);
@@ -409,9 +418,17 @@ int lm_apply_host(lm_engine* e, int slot, int fill_slot, const void* vol_host, i
 int lm_profile_enable(lm_engine* e, int on) {
     if (!e) return LM_ERR_INVALID;
     e->prof.on = on != 0;
-    e->prof.per_layer = on == 2;
+    e->prof.per_layer = on == 2 || on == 4;
     e->prof.dominant_only = on == 3;
+    e->prof.timeline = on == 4;
     return LM_OK;
+}
+int lm_profile_timeline(lm_engine* e, lm_launch_span* out, int cap) {
+    if (!e) return LM_ERR_INVALID;
+    e->prof.collect();
+    const int n = (int)e->prof.spans.size();
+    for (int i = 0; i < n && i < cap && out; ++i) out[i] = e->prof.spans[i];
+    return n;
 }
 int lm_profile_reset(lm_engine* e) {
     if (!e) return LM_ERR_INVALID;

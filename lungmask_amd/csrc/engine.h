@@ -68,6 +68,7 @@ struct Model {
     float *head_w = nullptr, *head_b = nullptr;
     float* head_b_h3 = nullptr;  // head bias + head_w . (shift of the last conv): the head reads an r-form tensor
     float* zeros_h3 = nullptr;   // 1024 zeros: the "shift" a deferred-shift producer applies
+    float* fc_pack = nullptr;    // first conv for the fused loader (ConvParamsH3::fc_c): w[9][64] | bias[64] | bn scale[64]
     std::vector<void*> allocs;
     // The split-f16 path stores activations as f16 pairs: a model whose activations left the f16 range (detected by the
     // kernels' range guard) is pinned to the exact-fp32 kernels from then on.
@@ -81,10 +82,15 @@ struct Profiler {
     bool per_layer = false;  // lm_profile_enable(e, 2): one entry per conv shape instead of per kernel
     bool dominant_only = false;  // lm_profile_enable(e, 3): events around the conv3x3 launches only (bench.py's timed region)
     bool skipped = false;
+    bool timeline = false;  // lm_profile_enable(e, 4): keep every launch's span (lm_profile_timeline)
+    int lane = 0;           // forward lane of the launches being recorded (set by forward())
+    hipEvent_t t0 = nullptr;  // first recorded event since the last reset: origin of the timeline
+    std::vector<lm_launch_span> spans;
     struct Rec {
         int kind;
         hipEvent_t a, b;
         double flops, bytes;
+        int lane;
     };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
@@ -236,6 +242,7 @@ struct lm_engine {
     lm::SlabState slab;
     lm::Profiler prof;
     int precision = 1;  // 1 (default): split-f16 3-product; 0: exact fp32 matrix ops (lm_set_precision)
+    int fusion = 7;     // lm_set_fusion: bit 0 first conv in conv 2's loader, bit 1 bilinear x2 in the decoder conv's loader, bit 2 split-K 1x1
     char* zero_page = nullptr;
     // lm_apply_host: the volume arrives in two pieces (the first two batches on the main stream, the rest on copy_stream while
     // they are computed); `tail_ready` is recorded behind the second piece, the hot path waits for it before it touches

@@ -156,6 +156,12 @@ __device__ __forceinline__ void lm_dma16(const lm_rsrc& r, unsigned voff, unsign
 __device__ __forceinline__ void lm_dma4_global(const void* gsrc, void* lds_wave_base) {
     memcpy((char*)lds_wave_base + (lm_emu::linear_tid() & 63) * 4, gsrc, 4);
 }
+__device__ __forceinline__ void lm_dma4(const lm_rsrc& r, unsigned voff, unsigned soff, void* lds_wave_base) {
+    char* d = (char*)lds_wave_base + (lm_emu::linear_tid() & 63) * 4;
+    const unsigned long long off = (unsigned long long)voff + soff;
+    if (off + 4 <= r.bytes) memcpy(d, r.base + off, 4);
+    else memset(d, 0, 4);
+}
 __device__ __forceinline__ void lm_barrier_dma() { __syncthreads(); }
 __device__ __forceinline__ void lm_barrier_lds() { __syncthreads(); }
 #define LM_PIN(x) \
@@ -174,6 +180,14 @@ __device__ __forceinline__ lm_rsrc lm_make_rsrc(const void* base, size_t bytes) 
 }
 __device__ __forceinline__ void lm_dma16(lm_rsrc r, unsigned voff, unsigned soff, void* lds_wave_base) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base), "v"(voff), "s"(r), "s"(soff)
+                 : "memory");
+}
+// 4-byte form of the buffer-descriptor DMA (buffer_load_dword ... offen lds): 64 lanes fill 256 contiguous LDS bytes, lanes whose
+// offset lies outside the buffer write zero; inactive lanes (EXEC = 0) write nothing
+__device__ __forceinline__ void lm_dma4(lm_rsrc r, unsigned voff, unsigned soff, void* lds_wave_base) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dword %1, %2, %3 offen lds"
                  :
                  : "s"((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base), "v"(voff), "s"(r), "s"(soff)
                  : "memory");
@@ -359,6 +373,24 @@ __device__ __forceinline__ void lm_unsplit4(uint2 hi, uint2 lo, float* out) {
     out[1] = r[1];
     out[2] = r[2];
     out[3] = r[3];
+#endif
+}
+
+// Two fp32 values in one 64-bit register pair, and acc += x[SEL] * w on both halves: v_pk_fma_f32 with one dword of x broadcast
+// (two independent IEEE fused multiply-adds -- the same bits as two fmaf calls).
+#ifdef LM_EMU_BUILD
+typedef float lm_f32x2 __attribute__((vector_size(8)));
+#else
+typedef float lm_f32x2 __attribute__((ext_vector_type(2)));
+#endif
+template <int SEL>
+__device__ __forceinline__ void lm_pk_fma_bcast(lm_f32x2& acc, lm_f32x2 x, lm_f32x2 w) {
+#ifdef LM_EMU_BUILD
+    acc[0] = fmaf(x[SEL], w[0], acc[0]);
+    acc[1] = fmaf(x[SEL], w[1], acc[1]);
+#else
+    if (SEL == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(x), "v"(w));
+    else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(x), "v"(w));
 #endif
 }
 

@@ -89,8 +89,12 @@ void Profiler::begin(hipStream_t s, int kind, double flops, double bytes) {
         skipped = true;
         return;
     }
-    Rec r{kind, get_event(), get_event(), flops, bytes};
+    Rec r{kind, get_event(), get_event(), flops, bytes, lane};
     (void)hipEventRecord(r.a, s);
+    if (timeline && t0 == nullptr) {
+        t0 = get_event();
+        (void)hipEventRecord(t0, s);
+    }
     recs.push_back(r);
 }
 void Profiler::end(hipStream_t s) {
@@ -107,6 +111,17 @@ void Profiler::collect() {
             memset(&st, 0, sizeof st);
             strncpy(st.name, names[r.kind].c_str(), sizeof(st.name) - 1);
         }
+        if (timeline && t0 != nullptr) {
+            lm_launch_span sp{};
+            strncpy(sp.name, names[r.kind].c_str(), sizeof(sp.name) - 1);
+            sp.lane = r.lane;
+            float ta = 0.f;
+            (void)hipEventSynchronize(t0);
+            (void)hipEventElapsedTime(&ta, t0, r.a);
+            sp.start_ms = ta;
+            sp.end_ms = (double)ta + ms;
+            spans.push_back(sp);
+        }
         st.launches++;
         st.total_ms += ms;
         st.flops += r.flops;
@@ -119,6 +134,9 @@ void Profiler::collect() {
 void Profiler::reset() {
     collect();
     acc.clear();
+    spans.clear();
+    if (t0 != nullptr) pool.push_back(t0);
+    t0 = nullptr;
 }
 void Profiler::release() {
     collect();
@@ -345,6 +363,20 @@ int model_load(lm_engine* e, int slot, const lm_tensor* tensors, int n) {
         LM_TRY(upload(md, hb, &md.head_b_h3));
         LM_TRY(upload(md, std::vector<float>(1024, 0.f), &md.zeros_h3));
     }
+    {   // the first conv as the fused loader of its consumer wants it (ConvParamsH3::fc_c): the arrays load_conv uploaded, in one piece
+        const lm_tensor* w = tm.get("down_path.0.block.0.weight", 64 * 9);
+        const lm_tensor* b = tm.get("down_path.0.block.0.bias", 64);
+        const lm_tensor* g = tm.get("down_path.0.block.2.weight", 64);
+        const lm_tensor* var = tm.get("down_path.0.block.2.running_var", 64);
+        if (!w || !b || !g || !var) return LM_ERR_INVALID;
+        std::vector<float> pk(9 * 64 + 128);
+        for (int o = 0; o < 64; ++o) {
+            for (int t = 0; t < 9; ++t) pk[(size_t)t * 64 + o] = w->data[(size_t)o * 9 + t];
+            pk[576 + o] = b->data[o];
+            pk[640 + o] = (float)((double)g->data[o] / std::sqrt((double)var->data[o] + 1e-5));
+        }
+        LM_TRY(upload(md, pk, &md.fc_pack));
+    }
     md.loaded = true;
     return LM_OK;
 }
@@ -365,7 +397,8 @@ struct Fwd {
     int abl = 0;              // LM_LAB_HOOKS builds only: kernels left out by tools/bw_tail_ablation.py
 
     int conv(const ConvLayer& L, const float* in, int in_cs, int in_co, int H, int W, float* out, int out_cs, int out_co,
-             float* pool = nullptr, int pool_cs = 0, int pool_co = 0, const HeadParams* head = nullptr) {
+             float* pool = nullptr, int pool_cs = 0, int pool_co = 0, const HeadParams* head = nullptr, const float* fc_x = nullptr,
+             const float* fc_c = nullptr) {
         if ((abl & 2) && L.taps == 1) return LM_OK;
         ConvParams p{};
         p.in = in;
@@ -425,6 +458,10 @@ struct Fwd {
                 static const double lim_mb = [] { const char* v = getenv("LM_STREAM_OUT_MB"); return v ? atof(v) : 128.0; }();
                 q.stream_out = px * L.cout * 4.0 > lim_mb * 1048576.0 ? 1 : 0;
             }
+            if (fc_x != nullptr) {  // the first layer runs inside this conv's loader (forward() has checked that it can)
+                q.fc_x = fc_x;
+                q.fc_c = fc_c;
+            }
             if (head && head->labels && !head->logp && L.taps == 9 && conv3x3_h3_can_fuse_head(q)) {
                 q.head_w = head->w;
                 q.head_b = head->bias;
@@ -459,6 +496,7 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
     const Model& md = e->models[slot];
     NNWorkspace& ws = lane ? e->nn2 : e->nn;
     hipStream_t stream = lane ? e->stream2 : e->stream;
+    e->prof.lane = lane;
     const size_t px = (size_t)B * H * W;
     LM_TRY(ws.t1.reserve(px * 64 * 4));
     LM_TRY(ws.t2.reserve(px * 16 * 4));
@@ -498,7 +536,16 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
     // 256 MB memory-side cache was measured in round 3 and gains nothing -- profiles/r03k_l0_subbatch.log: written data does not
     // stay there.)
     // ---- encoder (resunet.py:60-64)
-    if (!(abl & 1)) {
+    // The first conv (Cin = 1) is computed inside the loader of the second one whenever that conv runs on the persistent split-f16
+    // kernel with a deferred shift: its 64-channel output tensor is then neither written nor read (nn_kernels_h3.hip, PROD = 1).
+    bool fuse_first = false;
+    if (h3 && f.defer && (e->fusion & 1)) {
+        ConvParamsH3 q{};
+        q.B = B; q.H = H; q.W = W; q.Cin = 64; q.Cout = 64; q.in_cstride = 64;
+        q.bn_s = md.down[0][1].bn_s;
+        fuse_first = conv3x3_h3_can_fuse_first(q);
+    }
+    if (!(abl & 1) && !fuse_first) {
         FirstConvParams p{x, md.first.w, md.first.bias, md.first.bn_s, f.defer ? md.zeros_h3 : md.first.bn_t, t1, 64, 0, B, H, W, h3 ? e->range_flag : nullptr};
         e->prof.begin(stream, f.kfirst, 2.0 * px * 64 * 9, 4.0 * px * 65);
         hipError_t err = h3 ? launch_first_conv_h3(p, stream) : launch_first_conv(p, stream);
@@ -512,7 +559,8 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
         const int h = H >> i, w = W >> i, c = 64 << i;
         if (i > 0) LM_TRY(f.conv(md.down[i][0], ws.pool[i - 1].as<float>(), c / 2, 0, h, w, t1, c, 0));
         if (i < 4)  // skip tensor goes straight into the second half of the level's concat buffer, pooled copy alongside
-            LM_TRY(f.conv(md.down[i][1], t1, c, 0, h, w, ws.cat[i].as<float>(), 2 * c, c, ws.pool[i].as<float>(), c, 0));
+            LM_TRY(f.conv(md.down[i][1], t1, c, 0, h, w, ws.cat[i].as<float>(), 2 * c, c, ws.pool[i].as<float>(), c, 0, nullptr,
+                          (i == 0 && fuse_first) ? x : nullptr, md.fc_pack));
         else
             LM_TRY(f.conv(md.down[i][1], t1, c, 0, h, w, t3, c, 0));
     }

@@ -85,7 +85,15 @@ struct ConvParamsH3 {
     // the output tensor is far larger than the caches (the 256 x 256 and 128 x 128 levels of a 20-slice batch): its stores are
     // issued non-temporal, so that they do not evict the weights and halo rows the kernel re-reads
     int stream_out = 0;
+    // Fused first layer (down_path.0.block.0-2, Cin = 1; resunet.py:93-95): when fc_x is set this conv's INPUT tensor -- 64 channels
+    // in the deferred-shift form -- is never read from (or written to) memory: the loader of the persistent kernel computes it, 16
+    // channels at a time, from the network's 1-channel input with the arithmetic of first_conv_h3_kernel (same operation
+    // order: bit-identical tensors).  `in` is ignored.  Needs Cin == 64, W % 32 == 0 and a deferred BatchNorm shift.
+    const float* fc_x = nullptr;  // [B][H][W] f32
+    const float* fc_c = nullptr;  // 704 floats: w[9][64] | bias[64] | bn_s[64]
 };
+// whether launch_conv3x3_h3 can take the first layer into its loader for this shape (else run launch_first_conv_h3 first)
+bool conv3x3_h3_can_fuse_first(const ConvParamsH3& p);
 constexpr float kF16Guard = 32768.f;  // 2^15: a factor 2 below the largest finite half
 // whether launch_conv3x3_h3 can take the fused head for this shape (else run launch_head_h3 on the stored output)
 bool conv3x3_h3_can_fuse_head(const ConvParamsH3& p);

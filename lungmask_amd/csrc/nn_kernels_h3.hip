@@ -287,50 +287,77 @@ __device__ __forceinline__ float4 as_float4(const lm_h16x8& v) {
 #define H3P_MFMA1(F, I)                                                                                                           \
     accm[((I) >> 1) & 1][(I) & 1] = lm_mfma_f32_32x32x16_f16(F[((I) < 8 ? 0 : 2) + (((I) >> 1) & 1)],                             \
                                                             F[4 + 2 * ((I) & 1) + (((I) >> 2) == 1 ? 1 : 0)], accm[((I) >> 1) & 1][(I) & 1])
-#define H3P_MFMAS(F)             \
-    do {                         \
-        H3P_MFMA3(F, 0, 1, 2);   \
-        H3P_MFMA3(F, 3, 4, 5);   \
-        H3P_MFMA3(F, 6, 7, 8);   \
-        H3P_MFMA3(F, 9, 10, 11); \
+// (PS: the producer slot that runs beside these matrix instructions -- prod_step(PS, m), six micro-steps, one in front of every
+// pair; nothing at all when the instantiation has no producer)
+#define H3P_MFMA2(F, I0, I1) \
+    do {                     \
+        H3P_MFMA1(F, I0);    \
+        H3P_MFMA1(F, I1);    \
     } while (0)
-// the same with four DMA slots (K0 .. K0+3) spread between the matrix instructions
-#define H3P_MFMAS_D(F, K0)       \
-    do {                         \
-        H3P_MFMA3(F, 0, 1, 2);   \
-        dma_slot((K0) + 0);      \
-        H3P_MFMA3(F, 3, 4, 5);   \
-        dma_slot((K0) + 1);      \
-        H3P_MFMA3(F, 6, 7, 8);   \
-        dma_slot((K0) + 2);      \
-        H3P_MFMA3(F, 9, 10, 11); \
-        dma_slot((K0) + 3);      \
+#define H3P_MFMAS(F, PS)       \
+    do {                       \
+        prod_step(PS, 0);      \
+        H3P_MFMA2(F, 0, 1);    \
+        prod_step(PS, 1);      \
+        H3P_MFMA2(F, 2, 3);    \
+        prod_step(PS, 2);      \
+        H3P_MFMA2(F, 4, 5);    \
+        prod_step(PS, 3);      \
+        H3P_MFMA2(F, 6, 7);    \
+        prod_step(PS, 4);      \
+        H3P_MFMA2(F, 8, 9);    \
+        prod_step(PS, 5);      \
+        H3P_MFMA2(F, 10, 11);  \
+    } while (0)
+// the same with four DMA slots (K0 .. K0+3) spread between the matrix instructions (behind every third one)
+#define H3P_MFMAS_D(F, K0, PS) \
+    do {                       \
+        prod_step(PS, 0);      \
+        H3P_MFMA2(F, 0, 1);    \
+        prod_step(PS, 1);      \
+        H3P_MFMA1(F, 2);       \
+        dma_slot((K0) + 0);    \
+        H3P_MFMA1(F, 3);       \
+        prod_step(PS, 2);      \
+        H3P_MFMA2(F, 4, 5);    \
+        dma_slot((K0) + 1);    \
+        prod_step(PS, 3);      \
+        H3P_MFMA2(F, 6, 7);    \
+        prod_step(PS, 4);      \
+        H3P_MFMA1(F, 8);       \
+        dma_slot((K0) + 2);    \
+        H3P_MFMA1(F, 9);       \
+        prod_step(PS, 5);      \
+        H3P_MFMA2(F, 10, 11);  \
+        dma_slot((K0) + 3);    \
     } while (0)
 #define H3P_WAITF(N, F) LM_LDS_WAIT8(N, F[0], F[1], F[2], F[3], F[4], F[5], F[6], F[7])
 // one pipeline step: issue the reads of the NEXT tap into FN, wait for the current set FC, run its MFMAs
-#define H3P_STEP(FC, FN, AS, NDY, NDX) \
-    do {                               \
-        H3P_READS(FN, AS, NDY, NDX);   \
-        H3P_WAITF(8, FC);              \
-        H3P_MFMAS(FC);                 \
+// (PS: the producer slot of the step -- prod_step, 1 + the tap whose matrix instructions it runs beside; slot 0 lies beside the last
+// tap of the previous chunk, right behind the barrier that freed the buffer being filled)
+#define H3P_STEP(FC, FN, AS, NDY, NDX, PS) \
+    do {                                   \
+        H3P_READS(FN, AS, NDY, NDX);       \
+        H3P_WAITF(8, FC);                  \
+        H3P_MFMAS(FC, PS);                 \
     } while (0)
-#define H3P_STEP_D(FC, FN, AS, NDY, NDX, K0) \
-    do {                                     \
-        H3P_READS(FN, AS, NDY, NDX);         \
-        H3P_WAITF(8, FC);                    \
-        H3P_MFMAS_D(FC, K0);                 \
+#define H3P_STEP_D(FC, FN, AS, NDY, NDX, K0, PS) \
+    do {                                         \
+        H3P_READS(FN, AS, NDY, NDX);             \
+        H3P_WAITF(8, FC);                        \
+        H3P_MFMAS_D(FC, K0, PS);                 \
     } while (0)
 // taps 0..7 of the chunk in buffer AS (tap 0 already in flight in FA); leaves tap 8 in flight in FA
-#define H3P_CHUNK_STEPS(FA, FB, AS)          \
-    do {                                     \
-        H3P_STEP_D(FA, FB, AS, 0, 1, 0);     \
-        H3P_STEP_D(FB, FA, AS, 0, 2, 4);     \
-        H3P_STEP_D(FA, FB, AS, 1, 0, 8);     \
-        H3P_STEP(FB, FA, AS, 1, 1);          \
-        H3P_STEP(FA, FB, AS, 1, 2);          \
-        H3P_STEP(FB, FA, AS, 2, 0);          \
-        H3P_STEP(FA, FB, AS, 2, 1);          \
-        H3P_STEP(FB, FA, AS, 2, 2);          \
+#define H3P_CHUNK_STEPS(FA, FB, AS)             \
+    do {                                        \
+        H3P_STEP_D(FA, FB, AS, 0, 1, 0, 1);     \
+        H3P_STEP_D(FB, FA, AS, 0, 2, 4, 2);     \
+        H3P_STEP_D(FA, FB, AS, 1, 0, 8, 3);     \
+        H3P_STEP(FB, FA, AS, 1, 1, 4);          \
+        H3P_STEP(FA, FB, AS, 1, 2, 5);          \
+        H3P_STEP(FB, FA, AS, 2, 0, 6);          \
+        H3P_STEP(FA, FB, AS, 2, 1, 7);          \
+        H3P_STEP(FB, FA, AS, 2, 2, 8);          \
     } while (0)
 
 // HEAD: the fused-head form of the epilogue (last decoder conv, labels only) -- a separate instantiation, so that the 16 other
@@ -344,9 +371,28 @@ __device__ __forceinline__ float4 as_float4(const lm_h16x8& v) {
     } while (0)
 #define H3P_EPI_CL(MG) (32 * ((MG) >> 2) + 8 * ((MG) & 3) + 4 * kb)
 
-template <int TAPS, bool G16, bool HEAD = false>
+// ---- PROD = 1: the first layer of the network inside this kernel's loader (ConvParamsH3::fc_x) -------------------------------
+// The 64-channel input tensor of down_path.0's second conv is the first conv's output: one input channel, 9 multiply-adds, ReLU and
+// a scale per value (resunet.py:93-95) -- 16 MiB per slice written and read back for 37.7 MMAC.  In this form the tensor never
+// exists: per work item the 20 x 36 fp32 patch of the network input under the item's halo tile (grown by the first conv's own halo)
+// is DMA'd to LDS once (2.9 KB instead of 4 x 39 KB of activation chunks), and the activation image of 16-channel chunk c + 1 is
+// computed on the vector ALU -- the operation order of first_conv_h3_kernel, so the values are bit-identical -- and written to the
+// LDS buffer the DMA would have filled, in slices that run beside the matrix instructions of chunk c.  A task is (halo pixel,
+// 8-channel group): 612 x 2 per chunk.  Thread t takes pixel t for both groups (rounds 0 and 1: one read of the pixel's 3 x 3 input
+// neighbourhood serves both) and, for t < 200, pixel 512 + t % 100 for group t / 100 (round 2); a round is cut in two halves of 4
+// channels, a half runs beside the 12 matrix instructions of one tap in six micro-steps (LDS reads of the weights one step ahead
+// of the packed fused multiply-adds that use them), one in front of every matrix-instruction pair.
+namespace {
+constexpr int FC_PW = 36, FC_PH = 20, FC_PATCH = FC_PW * FC_PH;
+constexpr int FC_CONST = 9 * 64 + 64 + 64;  // w[9][64] | bias[64] | bn scale[64]
+constexpr int FC_TASKS = 18 * 34 * 2;
+
+}  // namespace
+
+template <int TAPS, bool G16, bool HEAD = false, int PROD = 0>
 __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptiles, int n_items, int xcd_order) {
     using SM = H3WSmem<TAPS, G16>;
+    static_assert(PROD == 0 || (TAPS == 9 && !G16 && !HEAD), "the loader-side producers belong to the 32-wide 3x3 form");
     constexpr int HALO = SM::HALO, PW = SM::PW, TWW = SM::TWW, NW = SM::NW, ROWB = PW * 64, NTSTEP = SM::NTSTEP;
     // Bank swizzle of the activation tile: 16-byte slot ^= (halo column >> ASWZ) & 3.  A ds_read_b128 lane group of 16
     // lanes spans 16 consecutive-ish columns of ONE row in the 32-wide geometry (>> 2 is conflict free for all three dx)
@@ -364,6 +410,10 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
     __shared__ __attribute__((aligned(1024))) char lds[2 * SUB * SM::BUF_BYTES + STAGE_EXTRA];
     __shared__ __attribute__((aligned(16))) float epi[2][3][TN];  // bias, bn scale, bn shift of the item (double buffered)
     __shared__ __attribute__((aligned(16))) float hw[HEAD ? kMaxClasses * 64 + kMaxClasses : 4];  // fused head: weights, bias
+    // fused first layer: input patches of the running and the next item, the first conv's constants (with the two chunk buffers and
+    // the epilogue constants this fills the CU's 160 KB to within ~100 bytes)
+    __shared__ __attribute__((aligned(16))) float fcx[PROD == 1 ? 2 * FC_PATCH : 4];
+    __shared__ __attribute__((aligned(16))) float fcc[PROD == 1 ? FC_CONST : 4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = lm_uniform(tid >> 6);
     const int li = lane & 31, kb = lane >> 5;
@@ -391,7 +441,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
         const int piece = wave + NW * j, idx = piece * 64 + lane;
         pyx[j] = -1;
         relA[j] = 0;
-        if (piece < SM::A_PIECES && idx < SM::A_ROWS * 4) {
+        if (PROD != 1 && piece < SM::A_PIECES && idx < SM::A_ROWS * 4) {
             const int row = idx >> 2;
             const int sl = row / SM::SL_ROWS, rr = row - sl * SM::SL_ROWS;
             const int py = rr / PW, px = rr - py * PW;
@@ -409,7 +459,8 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
     }
     const unsigned w_piece_stride = (unsigned)(NW * 64 / 4 / TN) * (unsigned)p.Cout * (unsigned)p.Cin * 4u;
     const unsigned slice_bytes = (unsigned)p.H * (unsigned)p.W * (unsigned)p.in_cstride * 4u;
-    const lm_rsrc rsrcA = lm_make_rsrc(p.in + (size_t)p.in_coff * 4, (size_t)p.B * slice_bytes - (size_t)p.in_coff * 4);
+    const lm_rsrc rsrcA = PROD == 1 ? lm_make_rsrc(p.fc_x, (size_t)p.B * p.H * p.W * 4)  // the network input: fp32 [B][H][W]
+                                    : lm_make_rsrc(p.in + (size_t)p.in_coff * 4, (size_t)p.B * slice_bytes - (size_t)p.in_coff * 4);
     const lm_rsrc rsrcW = lm_make_rsrc(p.w, (size_t)TAPS * p.Cout * p.Cin * 4);
     const int tiles_x = p.W / TWW;
     const int nchunks = p.Cin / KC;  // even (checked by the launcher)
@@ -452,6 +503,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
     };
     // per-lane source offsets of the halo tile of item (b, y0, x0), relative to slice b of rsrcA
     auto item_voffs = [&](int b, int y0, int x0, unsigned* voff) __attribute__((always_inline)) {
+        if constexpr (PROD == 1) return;  // no activation DMA: the loader computes the tile
         const int ioff = ((y0 - HALO) * p.W + (x0 - HALO)) * p.in_cstride * 4;  // may be negative; the sum below is not
 #pragma unroll
         for (int j = 0; j < SM::A_PER_WAVE; ++j) {
@@ -467,13 +519,44 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
     unsigned d_soffA = 0, d_soffW = 0;
     char* d_buf = lds;
     int d_nA = 0, d_nW = 0, d_epi = -1, d_n0 = 0;  // piece counts (0: nothing to stage); epi buffer to fill or -1
+    // ---- the producer's stage (PROD != 0): the chunk image the vector ALU computes beside the running taps
+    bool pr_on = false;  // wave-uniform
+    int pr_c0 = 0, pr_y0 = 0, pr_x0 = 0, pr_par = 0;
+    char* pr_buf = lds;
+    lm_f32x2 pr_x[5];      // a pixel's 3 x 3 input neighbourhood (taps 2 i, 2 i + 1), kept for the half-tasks that share it
+    lm_f32x4 pr_w[5];      // weight / constant reads in flight (issued one micro-step ahead of their use)
+    lm_f32x2 pr_a[2];      // the half-task's four channel accumulators
+    unsigned pr_max = 0u;  // f16 range guard of the values the producer writes
+    // this thread's two halo pixels (item invariant): py | px << 8, byte offset of the pixel's group-0 hi slot in a chunk image
+    int pr_pyx[2] = {0, 0}, pr_woff[2] = {0, 0};
+    if constexpr (PROD == 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pxl = i == 0 ? tid : 512 + (tid % 100);
+            const int py = pxl / 34, px = pxl - 34 * py;
+            pr_pyx[i] = py | (px << 8);
+            pr_woff[i] = pxl * 64 + (((px >> 2) & 3) << 4);  // logical slot 0 at physical slot (px >> 2) & 3; slot s at ^ (s << 4)
+        }
+    }
+    int it = blockIdx.x;
+    int b, y0, x0, n0;
+    int nb = 0, ny0 = 0, nx0 = 0, nn0 = 0;
+    int epar = 0;
     auto set_dma = [&](bool next_item, int b, int n0, int c0, int par, bool on, int epar_or_neg) __attribute__((always_inline)) {
+        if constexpr (PROD == 1) {
+            pr_on = on;
+            pr_c0 = c0;
+            pr_buf = lds + par * SM::BUF_BYTES;
+            pr_y0 = next_item ? ny0 : y0;
+            pr_x0 = next_item ? nx0 : x0;
+            pr_par = next_item ? (epar ^ 1) : epar;  // the patch buffer of the item the chunk belongs to
+        }
         d_next = next_item;
         d_soffA = (unsigned)b * slice_bytes + (unsigned)c0 * 4u;
         d_soffW = ((unsigned)n0 * (unsigned)p.Cin + (unsigned)c0) * 4u;
         d_buf = lds + par * SM::BUF_BYTES;
         on = on && !LM_ABL_DMA(c0);
-        d_nA = on ? SM::A_PIECES : 0;
+        d_nA = (on && PROD != 1) ? SM::A_PIECES : 0;
         d_nW = on ? SM::W_PIECES : 0;
         d_epi = on ? epar_or_neg : -1;
         d_n0 = n0;
@@ -500,9 +583,114 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
         }
     };
 
+    // Producer slot S of the stage (S = 0: beside the last tap of the previous chunk, 1 + t: beside tap t), micro-step m = 0..5 in
+    // front of the m-th matrix-instruction pair.  Half h of round r runs in slot PROD_S0 + 2 r + h; everything a slot writes is
+    // published by the chunk barrier behind tap 7.  The statement order is pinned (LM_SCHED_FENCE): reads one micro-step -- two
+    // matrix instructions of this wave, two of its SIMD partner -- ahead of their use.
+#ifndef LM_PROD_S0
+#define LM_PROD_S0 1
+#endif
+    constexpr int PROD_S0 = LM_PROD_S0;
+    // (slot 0 does not exist for the stage that fills chunk 1 of an item -- it starts behind the item switch, not behind a tap 8 --
+    // and slot 8 lies behind the barrier that publishes the image)
+    static_assert(PROD_S0 >= 1 && PROD_S0 + 5 <= 7, "producer slots must lie beside taps 0..6 of the running chunk");
+    auto prod_step = [&](int S, int m) __attribute__((always_inline)) {
+        if constexpr (PROD == 1) {
+            const int hs = S - PROD_S0;
+            if (hs < 0 || hs >= 6) return;
+            const int r = hs >> 1, half = hs & 1, pi = r == 2 ? 1 : 0;
+            if (!pr_on) return;
+            LM_SCHED_FENCE();
+            if (r < 2 || tid < 200) {
+                const int grp = r == 2 ? (tid >= 100 ? 1 : 0) : r;
+                const int py = pr_pyx[pi] & 0xff, px = pr_pyx[pi] >> 8;
+                const float* cw = fcc + pr_c0 + 8 * grp + 4 * half;  // this half-task's 4 channels: w[k] at + 64 k, bias + 576, scale + 640
+                auto ldw = [&](int i) { return *reinterpret_cast<const lm_f32x4*>(cw + i * 64); };
+                auto fma2 = [&](int k, const lm_f32x4& w) __attribute__((always_inline)) {  // tap k on the four channels
+                    const lm_f32x2 w01 = {w[0], w[1]}, w23 = {w[2], w[3]};
+                    if (k & 1) {
+                        lm_pk_fma_bcast<1>(pr_a[0], pr_x[k >> 1], w01);
+                        lm_pk_fma_bcast<1>(pr_a[1], pr_x[k >> 1], w23);
+                    } else {
+                        lm_pk_fma_bcast<0>(pr_a[0], pr_x[k >> 1], w01);
+                        lm_pk_fma_bcast<0>(pr_a[1], pr_x[k >> 1], w23);
+                    }
+                };
+                if (m == 0) {
+                    if (half == 0 && r != 1) {  // the pixel's 3 x 3 input neighbourhood (the patch starts one more pixel up and left)
+                        const float* xp = fcx + pr_par * FC_PATCH + py * FC_PW + px;
+                        pr_x[0] = lm_f32x2{xp[0], xp[1]};
+                        pr_x[1] = lm_f32x2{xp[2], xp[FC_PW]};
+                        pr_x[2] = lm_f32x2{xp[FC_PW + 1], xp[FC_PW + 2]};
+                        pr_x[3] = lm_f32x2{xp[2 * FC_PW], xp[2 * FC_PW + 1]};
+                        pr_x[4] = lm_f32x2{xp[2 * FC_PW + 2], 0.f};
+                    }
+                    pr_w[0] = ldw(9);  // bias
+                    pr_w[1] = ldw(0);
+                    pr_w[2] = ldw(1);
+                } else if (m == 1) {
+                    pr_w[3] = ldw(2);
+                    pr_w[4] = ldw(3);
+                    // first_conv_h3_kernel's chain: bias, then taps 0..8
+                    pr_a[0] = lm_f32x2{pr_w[0][0], pr_w[0][1]};
+                    pr_a[1] = lm_f32x2{pr_w[0][2], pr_w[0][3]};
+                    fma2(0, pr_w[1]);
+                    fma2(1, pr_w[2]);
+                } else if (m == 2) {
+                    pr_w[0] = ldw(4);
+                    pr_w[1] = ldw(5);
+                    fma2(2, pr_w[3]);
+                    fma2(3, pr_w[4]);
+                } else if (m == 3) {
+                    pr_w[2] = ldw(6);
+                    pr_w[3] = ldw(7);
+                    fma2(4, pr_w[0]);
+                    fma2(5, pr_w[1]);
+                } else if (m == 4) {
+                    pr_w[0] = ldw(8);
+                    pr_w[1] = ldw(10);  // BatchNorm scale
+                    fma2(6, pr_w[2]);
+                    fma2(7, pr_w[3]);
+                } else {
+                    fma2(8, pr_w[0]);
+                    // ReLU, BatchNorm scale; the shift is deferred to this conv's bias and border table (fmaf(., s, 0): what the
+                    // stand-alone kernel evaluates with its zero shift array)
+                    const float v0 = fmaf(fmaxf(pr_a[0][0], 0.f), pr_w[1][0], 0.f), v1 = fmaf(fmaxf(pr_a[0][1], 0.f), pr_w[1][1], 0.f);
+                    const float v2 = fmaf(fmaxf(pr_a[1][0], 0.f), pr_w[1][2], 0.f), v3 = fmaf(fmaxf(pr_a[1][1], 0.f), pr_w[1][3], 0.f);
+                    // zero padding of THIS conv: halo pixels outside the image are 0 (one unsigned compare per axis)
+                    const bool inside = (unsigned)(pr_y0 - 1 + py) < (unsigned)p.H && (unsigned)(pr_x0 - 1 + px) < (unsigned)p.W;
+                    uint2 ph, plo;
+                    lm_split4(v0, v1, v2, v3, &ph, &plo);
+                    if (!inside) {
+                        ph.x = ph.y = 0u;
+                        plo.x = plo.y = 0u;
+                    }
+                    pr_max = lm_pk_absmax_u16(lm_pk_absmax_u16(pr_max, ph.x), ph.y);
+                    const int off = (pr_woff[pi] ^ (grp << 5)) + half * 8;  // group g: logical slots 2 g (hi), 2 g + 1 (lo)
+                    *reinterpret_cast<uint2_a*>(pr_buf + off) = ph;
+                    *reinterpret_cast<uint2_a*>(pr_buf + (off ^ 16)) = plo;
+                }
+            }
+            LM_SCHED_FENCE();
+        }
+    };
+    // the 20 x 36 input patch of item (b, y0, x0) -> fcx[par]: 12 DMA pieces of 64 floats (the last one 16), 1-2 per wave
+    auto fc_patch_dma = [&](int b, int y0, int x0, int par) __attribute__((always_inline)) {
+        if constexpr (PROD == 1) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int piece = wave + NW * j, idx = piece * 64 + lane;
+                if (piece < (FC_PATCH + 63) / 64 && idx < FC_PATCH) {  // (the partial piece runs with the other lanes masked off)
+                    const int py = idx / FC_PW, px = idx - py * FC_PW;
+                    const int gy = y0 - 2 + py, gx = x0 - 2 + px;
+                    const bool inb = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+                    lm_dma4(rsrcA, inb ? (unsigned)(((b * p.H + gy) * p.W + gx) * 4) : LM_DMA_OOB, 0u, fcx + par * FC_PATCH + piece * 64);
+                }
+            }
+        }
+    };
+
     lm_f32x16 accm[2][2];  // [M-tile][N-tile = row]: all three products of the split scheme accumulate here
-    int it = blockIdx.x;
-    int b, y0, x0, n0;
     while (it < n_items && !decode(it, b, y0, x0, n0)) it += gridDim.x;
     if (it >= n_items) return;
     if (!bn && tid < 2 * TN) {  // no BatchNorm (decoder 1x1): identity constants, never overwritten
@@ -515,13 +703,21 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
         if (tid < p.head_C) hw[kMaxClasses * 64 + tid] = p.head_b[tid];
     }
     item_voffs(b, y0, x0, voffC);
-    int epar = 0;
     char* const buf0 = lds;
     char* const buf1 = lds + SUB * SM::BUF_BYTES;
     // prologue: stage 0 of the first item, all pieces at once (set_dma's buffer argument counts chunk images)
     set_dma(false, b, n0, 0, 0, true, epar);
 #pragma unroll
     for (int k = 0; k < N_SLOTS; ++k) dma_slot(k);
+    if constexpr (PROD == 1) {  // the first item's chunk 0 is computed here, with nothing to run beside
+        for (int i = tid; i < FC_CONST; i += 512) fcc[i] = p.fc_c[i];
+        fc_patch_dma(b, y0, x0, 0);
+        lm_barrier_dma();
+#pragma unroll
+        for (int S = PROD_S0; S < PROD_S0 + 6; ++S)
+#pragma unroll
+            for (int m = 0; m < 6; ++m) prod_step(S, m);
+    }
     if (SUB == 2) {
         set_dma(false, b, n0, KC, 1, true, -1);
 #pragma unroll
@@ -539,10 +735,12 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                     accm[i][j][r] = 0.f;
                 }
         int nit = it + gridDim.x;
-        int nb = 0, ny0 = 0, nx0 = 0, nn0 = 0;
         while (nit < n_items && !decode(nit, nb, ny0, nx0, nn0)) nit += gridDim.x;
         const bool have_next = nit < n_items;
         item_voffs(nb, ny0, nx0, voffN);
+        // (fused first layer) the next item's input patch: its buffer was last read while the previous item's chunk 2 ran, the
+        // barrier of this item's chunk 0 publishes it, and it is first read beside this item's last chunk
+        if (have_next) fc_patch_dma(nb, ny0, nx0, epar ^ 1);
         // chunk 0 of this item is resident in buffer 0 (and visible: a barrier lies behind its DMA wait)
         lm_h16x8 f[8], g[8];  // two fragment sets: whi0 whi1 wlo0 wlo1 a0hi a0lo a1hi a1lo
         bool abl_r = false;   // lab ablation (constant false in the product)
@@ -560,7 +758,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                 H3P_READS(g, buf1, 0, 0);
                 if (ci + 2 < nchunks) set_dma(false, b, n0, (ci + 2) * KC, 0, true, -1);
                 else set_dma(true, nb, nn0, 0, 0, have_next, epar ^ 1);  // the next item's chunk 0 + epilogue constants
-                H3P_MFMAS(f);
+                H3P_MFMAS(f, 0);
                 // ---- odd chunk ci + 1 (buffer 1), fragments start in g
                 H3P_CHUNK_STEPS(g, f, buf1);
                 H3P_WAITF(0, g);
@@ -573,7 +771,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                 } else {
                     set_dma(false, b, n0, 0, 1, false, -1);  // buffer 1 becomes the epilogue's staging area
                 }
-                H3P_MFMAS(g);
+                H3P_MFMAS(g, 0);
             }
         } else {
             // 1x1: stage si = chunks 2 si, 2 si + 1 (two chunk images side by side), resident in stage buffer si & 1; the number of
@@ -592,9 +790,9 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                 H3P_READS(f, as, 0, 0);
                 H3P_READS(g, as + SM::BUF_BYTES, 0, 0);
                 H3P_WAITF(8, f);
-                H3P_MFMAS(f);
+                H3P_MFMAS(f, -1);
                 H3P_WAITF(0, g);
-                H3P_MFMAS(g);
+                H3P_MFMAS(g, -1);
                 lm_barrier_dma();
             }
         }
@@ -853,6 +1051,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
         lm_barrier_lds();
         LM_TRACE_MARK(4);
     }
+    if (PROD != 0 && p.range_flag != nullptr && lm_pk_out_of_f16_guard(pr_max)) atomicOr(p.range_flag, 1u);
     LM_TRACE_FLUSH();
 }
 
@@ -890,6 +1089,7 @@ static hipError_t launch_conv_h3_t(const ConvParamsH3& p, hipStream_t stream) {
             pd.out = p.out + (size_t)b0 * p.H * p.W * p.out_cstride * 4;
             if (p.pool) pd.pool = p.pool + (size_t)b0 * (p.H / 2) * (p.W / 2) * p.pool_cstride * 4;
             if (p.head_labels) pd.head_labels = p.head_labels + (size_t)b0 * p.H * p.W;
+            if (p.fc_x) pd.fc_x = p.fc_x + (size_t)b0 * p.H * p.W;
             const int n_ptiles = g16 ? ((p.H + TH - 1) / TH) * ((pd.B + 1) / 2) : (p.W / 32) * ((p.H + TH - 1) / TH) * pd.B;
             const int n_ct = p.Cout / TN;
             const int xcd_order = order_env >= 0 ? order_env : (n_ct >= 2 && n_ptiles >= 64 ? 1 : 0);
@@ -901,6 +1101,8 @@ static hipError_t launch_conv_h3_t(const ConvParamsH3& p, hipStream_t stream) {
                 LM_LAUNCH((conv_igemm_h3p<TAPS, true>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
             else if (TAPS == 9 && pd.head_labels != nullptr)
                 LM_LAUNCH((conv_igemm_h3p<9, false, true>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
+            else if (TAPS == 9 && pd.fc_x != nullptr)
+                LM_LAUNCH((conv_igemm_h3p<9, false, false, 1>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
             else
                 LM_LAUNCH((conv_igemm_h3p<TAPS, false>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
             const hipError_t err = hipGetLastError();
@@ -919,7 +1121,13 @@ bool conv3x3_h3_can_fuse_head(const ConvParamsH3& p) {
     return allow && p.Cout == TN && p.W % 32 == 0 && h3_persistent_ok(p, 9);
 }
 
+bool conv3x3_h3_can_fuse_first(const ConvParamsH3& p) {
+    static const bool allow = [] { const char* e = getenv("LM_H3_FUSE_FIRST"); return !(e && e[0] == '0'); }();  // A/B hook
+    return allow && p.Cin == 64 && p.W % 32 == 0 && p.head_labels == nullptr && h3_persistent_ok(p, 9);
+}
+
 hipError_t launch_conv3x3_h3(const ConvParamsH3& p, hipStream_t stream) {
+    if (p.fc_x != nullptr && (!conv3x3_h3_can_fuse_first(p) || !p.fc_c)) return hipErrorInvalidValue;
     if (p.head_labels != nullptr && (!conv3x3_h3_can_fuse_head(p) || p.head_C < 1 || p.head_C > kMaxClasses || !p.head_w || !p.head_b))
         return hipErrorInvalidValue;
     return launch_conv_h3_t<9>(p, stream);

@@ -47,6 +47,23 @@ def test_fused_head_is_bit_identical_to_the_head_kernel(emu_engine, golden_dir):
         assert np.array_equal(lab_fused, lab_plain) and np.array_equal(lab_plain, logp.argmax(1))
 
 
+def test_first_conv_inside_the_loader_is_bit_identical(emu_engine, golden_dir):
+    """lm_set_fusion bit 0: down_path.0's first conv (resunet.py:93-95) computed by the vector ALU inside the loader of its second conv
+    keeps the stand-alone kernel's operation order -- same labels, same log-probability bytes (32-wide geometry of the persistent
+    kernel, two work items per slice so that the item switch with its double-buffered input patch is exercised)."""
+    g = np.load(os.path.join(golden_dir, "unet_c3.npz"))
+    emu_engine.load_state_dict(0, uo.synthetic_state_dict(3))
+    x = np.concatenate([g["rand32_x"][:1].reshape(1, 32, 32)] * 2, axis=2)  # one 32 x 64 slice
+    try:
+        emu_engine.set_fusion(0)
+        lab0, logp0 = emu_engine.forward(0, x)
+        emu_engine.set_fusion(7)
+        lab1, logp1 = emu_engine.forward(0, x)
+    finally:
+        emu_engine.set_fusion(7)
+    assert np.array_equal(lab0, lab1) and np.array_equal(logp0, logp1)
+
+
 def out_of_f16_range_state_dict(c=3, scale=1e5):
     """A model whose FIRST layer's activations are ~1e5 (beyond the f16 maximum of 65504) while everything behind it is
     ordinary: the first BatchNorm's affine is scaled up and the second conv's weights down by the same factor (the reference

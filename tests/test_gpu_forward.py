@@ -42,6 +42,28 @@ def test_forward_matches_reference_goldens(gpu_engine, golden_dir, C, precision)
         check_labels(lab, g[case + "_lab"], g[case + "_margin"].astype(np.float32), TOL)
 
 
+def test_loader_side_fusions_are_bit_identical(gpu_engine):
+    """lm_set_fusion: the first conv computed inside the loader of conv 2 (resunet.py:93-95), the decoder's bilinear x2 inside the loader
+    of the block's first conv (resunet.py:131-133, 144-155) and the fixed-order split-K of the 16 x 16 1x1 conv keep the operation order
+    of the stand-alone kernels: labels AND log-probabilities are the same bytes for every mask, on widths that take the persistent
+    kernel (multiples of 32), the 16-wide geometry and the fallback kernel, and batches that leave a partial last work item."""
+    try:
+        for C in (3, 6):
+            gpu_engine.load_state_dict(0, uo.synthetic_state_dict(C))
+            for shape in ((3, 256, 256), (5, 64, 96), (2, 32, 32), (2, 48, 80), (3, 128, 32), (2, 16, 16)):
+                x = np.random.default_rng(shape[1] + C).random(shape, dtype=np.float32)
+                gpu_engine.set_fusion(0)
+                lab0, logp0 = gpu_engine.forward(0, x)
+                only0 = gpu_engine.forward(0, x, want_logp=False)[0]
+                for mask in (1, 2, 4, 7):
+                    gpu_engine.set_fusion(mask)
+                    lab, logp = gpu_engine.forward(0, x)
+                    only = gpu_engine.forward(0, x, want_logp=False)[0]
+                    assert np.array_equal(lab, lab0) and np.array_equal(logp, logp0) and np.array_equal(only, only0), (C, shape, mask)
+    finally:
+        gpu_engine.set_fusion(7)
+
+
 def test_forward_batch20_vs_oracle(gpu_engine, precision):
     """BASELINE config batch (20 slices of 256x256) against the torch-fp32 CPU oracle."""
     sd = uo.synthetic_state_dict(3)
