@@ -87,6 +87,11 @@ int lm_dev_alloc(lm_engine* e, void** dev_ptr, size_t bytes);
 int lm_dev_free(lm_engine* e, void* dev_ptr);
 int lm_copy_h2d(lm_engine* e, void* dev_dst, const void* host_src, size_t bytes);
 int lm_copy_d2h(lm_engine* e, void* host_dst, const void* dev_src, size_t bytes);
+/* Page-locked host memory for volumes / label arrays that cross the boundary (lm_apply_host): the device copies straight into and
+ * out of it at link speed, and a result block that is used again has no page faults to take.  The block belongs to the caller --
+ * the engine keeps no record of it and lm_engine_destroy does not free it; lm_host_free accepts e == NULL. */
+int lm_host_alloc(lm_engine* e, void** host_ptr, size_t bytes);
+int lm_host_free(lm_engine* e, void* host_ptr);
 
 /* ---- model (mask.py:38-68 get_model) ------------------------------------------ */
 /* Loads a U-Net state_dict into `slot` (0..3).  n_classes is taken from
@@ -185,10 +190,13 @@ int lm_apply_host(lm_engine* e, int slot, int fill_slot, const void* vol_host, i
 int lm_forward_batches_dev(lm_engine* e, int slot, const float* x_dev, int n, int h, int w, int batch_size,
                            uint8_t* labels_dev);
 int lm_set_streams(lm_engine* e, int n);
-/* Producer/consumer fusions of the split-f16 forward (default: all on; results are bit-identical either way -- A/B and test hook).
+/* Producer/consumer fusions of the split-f16 forward (default: all on = 15; A/B and test hook).
  * bit 0: down_path.0's first conv (Cin = 1, resunet.py:93-95) computed inside the loader of its second conv;
  * bit 1: the decoder's bilinear x2 (resunet.py:131-133) computed inside the loader of the block's first conv;
- * bit 2: fixed-order split-K for the 16 x 16 decoder 1x1 conv. */
+ * bit 2: fixed-order split-K for the 16 x 16 decoder 1x1 conv;
+ * bit 3: the head (last 1x1 conv + log-softmax + argmax, resunet.py:69-70, mask.py:184-186) inside the last conv's epilogue.
+ * Bits 0-2 keep the stand-alone kernels' operation order: bit-identical results.  Bit 3 evaluates the head on the last conv's fp32
+ * results instead of the stored 22-bit hi/lo tensor: log-probabilities differ in the last bits, labels on near-tie pixels only. */
 int lm_set_fusion(lm_engine* e, int mask);
 
 /* Per-kernel timing of the launches since the last reset (HIP events on the launching stream).

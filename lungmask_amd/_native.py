@@ -64,6 +64,9 @@ class Library:
         L.lm_dev_free.argtypes = [C.c_void_p, C.c_void_p]
         L.lm_copy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.lm_copy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        if hasattr(L, "lm_host_alloc"):
+            L.lm_host_alloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]
+            L.lm_host_free.argtypes = [C.c_void_p, C.c_void_p]
         L.lm_model_load.argtypes = [C.c_void_p, C.c_int, C.POINTER(_Tensor), C.c_int]
         L.lm_model_classes.argtypes = [C.c_void_p, C.c_int]
         if hasattr(L, "lm_engine_stream"):
@@ -189,6 +192,15 @@ class Engine:
     def sync(self):
         self.L.check(self.L.lib.lm_engine_sync(self.h), "lm_engine_sync")
 
+    def host_alloc(self, nbytes: int) -> int:
+        """Page-locked host memory (lm_host_alloc) -> address.  The caller owns it: free with host_free (also after close())."""
+        p = C.c_void_p()
+        self.L.check(self.L.lib.lm_host_alloc(self.h, C.byref(p), int(nbytes)), "lm_host_alloc")
+        return int(p.value)
+
+    def host_free(self, addr: int):
+        self.L.check(self.L.lib.lm_host_free(self.h if getattr(self, "h", None) else None, C.c_void_p(addr)), "lm_host_free")
+
     # -- model
     def load_state_dict(self, slot: int, state_dict: Dict[str, "np.ndarray"]) -> int:
         """state_dict: name -> array-like (torch tensors are converted with .numpy())."""
@@ -255,8 +267,9 @@ class Engine:
         self.L.check(self.L.lib.lm_set_streams(self.h, int(n)), "lm_set_streams")
 
     def set_fusion(self, mask: int):
-        """Bit 0: first conv inside conv 2's loader; bit 1: bilinear x2 inside the decoder conv's loader; bit 2: split-K 1x1.
-        Default 7; results are bit-identical for every mask (A/B and test hook)."""
+        """Bit 0: first conv inside conv 2's loader; bit 1: bilinear x2 inside the decoder conv's loader; bit 2: split-K 1x1 (all
+        three bit-identical to the stand-alone kernels); bit 3: head inside the last conv's epilogue (fp32 instead of the stored
+        22-bit tensor: differs in the last bits).  Default 15 (A/B and test hook)."""
         self.L.check(self.L.lib.lm_set_fusion(self.h, int(mask)), "lm_set_fusion")
 
     def forward_dev(self, slot: int, x: DeviceArray, labels: Optional[DeviceArray] = None, logp: Optional[DeviceArray] = None):

@@ -101,6 +101,36 @@ int lm_dev_free(lm_engine* e, void* dev_ptr) {
     LM_HIP(hipFree(dev_ptr));
     return LM_OK;
 }
+int lm_host_alloc(lm_engine* e, void** host_ptr, size_t bytes) {
+    if (!e || !host_ptr) return LM_ERR_INVALID;
+    LM_HIP(hipSetDevice(e->device));
+    LM_HIP(hipHostMalloc(host_ptr, bytes ? bytes : 16, 0));
+    return LM_OK;
+}
+int lm_host_free(lm_engine* e, void* host_ptr) {
+    if (e) LM_HIP(hipStreamSynchronize(e->stream));
+    if (host_ptr) LM_HIP(hipHostFree(host_ptr));
+    return LM_OK;
+}
+// whether [p, p + bytes) is page-locked memory the runtime knows (lm_host_alloc, hipHostMalloc, a registered range)
+static bool host_range_is_pinned(const void* p, size_t bytes) {
+#ifdef LM_EMU_BUILD
+    (void)p;
+    (void)bytes;
+    return false;
+#else
+    hipPointerAttribute_t a0{}, a1{};
+    if (hipPointerGetAttributes(&a0, p) != hipSuccess) {
+        (void)hipGetLastError();  // ordinary memory: "invalid value", not an error of ours
+        return false;
+    }
+    if (bytes > 1 && hipPointerGetAttributes(&a1, reinterpret_cast<const char*>(p) + bytes - 1) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a0.type == hipMemoryTypeHost && (bytes <= 1 || a1.type == hipMemoryTypeHost);
+#endif
+}
 int lm_copy_h2d(lm_engine* e, void* dev_dst, const void* host_src, size_t bytes) {
     if (!e) return LM_ERR_INVALID;
     LM_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, e->stream));
@@ -150,8 +180,8 @@ int lm_set_streams(lm_engine* e, int n) {
 }
 
 int lm_set_fusion(lm_engine* e, int mask) {
-    if (!e || mask < 0 || mask > 7) {
-        set_error("lm_set_fusion: mask is a combination of bits 0..2");
+    if (!e || mask < 0 || mask > 15) {
+        set_error("lm_set_fusion: mask is a combination of bits 0..3");
         return LM_ERR_INVALID;
     }
     e->fusion = mask;
@@ -354,6 +384,7 @@ int lm_apply_host(lm_engine* e, int slot, int fill_slot, const void* vol_host, i
             return LM_ERR_DEVICE;
         }
     }
+    const bool out_pinned = host_range_is_pinned(out_host, nvox);
     const bool threaded = e->helper.start();  // false: no thread could be created -- one copy on the main stream, no page touching
     if (!threaded) split = false;
     static const bool timing = [] { const char* v = getenv("LM_HOST_TIMING"); return v && v[0] == '1'; }();  // stderr breakdown of this call
@@ -377,9 +408,11 @@ int lm_apply_host(lm_engine* e, int slot, int fill_slot, const void* vol_host, i
             // (Pinning the caller's array here with hipHostRegister makes the copy back 0.4 ms faster -- tools/host_pin_probe.py -- but an
             // array from the malloc heap shares its first and last page with other objects and with the runtime's own cache of pinned
             // user ranges; one whole-suite run aborted inside the next model load after such a registration, so the pages are touched.)
-            volatile uint8_t* o = out_host;
-            for (size_t i = 0; i < nvox; i += 4096) o[i] = o[i];
-            if (nvox) o[nvox - 1] = o[nvox - 1];
+            if (!out_pinned) {  // (a page-locked block -- lm_host_alloc, what LMInferer hands out -- has no faults to take)
+                volatile uint8_t* o = out_host;
+                for (size_t i = 0; i < nvox; i += 4096) o[i] = o[i];
+                if (nvox) o[nvox - 1] = o[nvox - 1];
+            }
             t_touch = ms_since(t_start);
         });
     hipError_t err = hipMemcpyAsync(e->app.vol.p, vol_host, (size_t)(split ? head : n) * slice * esz, hipMemcpyHostToDevice, e->stream);

@@ -462,10 +462,11 @@ struct Fwd {
                 q.fc_x = fc_x;
                 q.fc_c = fc_c;
             }
-            if (head && head->labels && !head->logp && L.taps == 9 && conv3x3_h3_can_fuse_head(q)) {
+            if (head && head->labels && L.taps == 9 && (e->fusion & 8) && conv3x3_h3_can_fuse_head(q)) {
                 q.head_w = head->w;
                 q.head_b = head->bias;
                 q.head_labels = head->labels;
+                q.head_logp = head->logp;
                 q.head_C = head->C;
                 head_fused = true;
             }
@@ -582,7 +583,7 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
             }
         }
         LM_TRY(f.conv(md.upc[i][0], ws.cat[lvl].as<float>(), 2 * c, 0, h, w, t1, c, 0));
-        // the last conv takes the head (1x1 conv + argmax) into its epilogue when only labels are wanted
+        // the last conv takes the head (1x1 conv + argmax, + log-softmax when asked for) into its epilogue
         const HeadParams hp{t3, md.head_w, f.defer ? md.head_b_h3 : md.head_b, labels, logp, B, H, W, md.n_classes};
         LM_TRY(f.conv(md.upc[i][1], t1, c, 0, h, w, t3, c, 0, nullptr, 0, 0, i == 3 ? &hp : nullptr));
     }

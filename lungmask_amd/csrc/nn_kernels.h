@@ -69,10 +69,13 @@ struct ConvParamsH3 {
     const char* zeros;  // >= 16 zero bytes in device memory (source of out-of-image halo pixels)
     int B, H, W, Cin, Cout;
     // Fused head (last conv of the decoder, Cout == 64): when head_labels is set the conv output is NOT stored; the
-    // 1x1 head conv + argmax (resunet.py:69, mask.py:184-186) run in the epilogue, bit-identical to launch_head_h3.
+    // 1x1 head conv + argmax (resunet.py:69, mask.py:184-186) -- and, with head_logp, the log-softmax (resunet.py:70) -- run in the
+    // epilogue on the conv's fp32 results (launch_head_h3's summation order; that kernel reads the stored 22-bit tensor instead and
+    // may therefore differ from this path on near-tie pixels).
     const float* head_w = nullptr;   // [C][64]
     const float* head_b = nullptr;   // [C]
     uint8_t* head_labels = nullptr;  // [B][H][W]
+    float* head_logp = nullptr;      // [B][C][H][W] or nullptr
     int head_C = 0;
     // Border correction of a consumer of a deferred-shift ("r-form") tensor: [16][Cout] floats indexed by the pixel's border mask
     // (1 top row, 2 bottom row, 4 left column, 8 right column), SUBTRACTED from the bias for pixels on the image border; the

@@ -61,6 +61,18 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvParams p) {
     const float* __restrict__ in_b = p.in + (size_t)b * p.H * p.W * p.in_cstride + p.in_coff;
 
     for (int c0 = 0; c0 < p.Cin; c0 += KC) {
+        // Chunked accumulation: every 16-channel chunk (TAPS x 8 matrix steps of two products each) sums into a fresh accumulator
+        // that is added to the running one in chunk order.  The matrix op is a sequential fp32 chain -- one rounding per two
+        // products, up to 4608 in a row for K = 9216 -- and as ONE chain it was less accurate than torch's own blocked fp32 GEMM
+        // (6.4e-4 against the reference's 1.6e-4 distance to float64 on the Appendix-D head, round 3); 72 steps per chunk + one
+        // addition per chunk bound the error growth by sqrt(72) + sqrt(K / 144) instead of sqrt(K / 2).
+        lm_f32x16 cacc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cacc[i][j][r] = 0.f;
         __syncthreads();
         // ---- stage the activation halo tile: [PH*PW pixels][KC channels], zero outside the image
         for (int idx = tid; idx < PH * PW * (KC / 4); idx += 256) {
@@ -94,12 +106,18 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvParams p) {
             for (int kk = 0; kk < KC / 2; ++kk) {
                 const float a0 = a0p[2 * kk], a1 = a1p[2 * kk];
                 const float b0 = bp[2 * kk * TN], b1 = bp[2 * kk * TN + 32];
-                acc[0][0] = lm_mfma_f32_32x32x2(a0, b0, acc[0][0]);
-                acc[0][1] = lm_mfma_f32_32x32x2(a0, b1, acc[0][1]);
-                acc[1][0] = lm_mfma_f32_32x32x2(a1, b0, acc[1][0]);
-                acc[1][1] = lm_mfma_f32_32x32x2(a1, b1, acc[1][1]);
+                cacc[0][0] = lm_mfma_f32_32x32x2(a0, b0, cacc[0][0]);
+                cacc[0][1] = lm_mfma_f32_32x32x2(a0, b1, cacc[0][1]);
+                cacc[1][0] = lm_mfma_f32_32x32x2(a1, b0, cacc[1][0]);
+                cacc[1][1] = lm_mfma_f32_32x32x2(a1, b1, cacc[1][1]);
             }
         }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += cacc[i][j][r];
     }
 
     // ---- epilogue: bias (+ ReLU + BN affine) (+ 2x2 average pool), NHWC stores (128 B per half-wave)

@@ -360,8 +360,8 @@ __device__ __forceinline__ float4 as_float4(const lm_h16x8& v) {
         H3P_STEP(FB, FA, AS, 2, 2, 8);          \
     } while (0)
 
-// HEAD: the fused-head form of the epilogue (last decoder conv, labels only) -- a separate instantiation, so that the 16 other
-// launches of a forward do not carry its registers.
+// HEAD: the fused-head form of the epilogue (last decoder conv; 1: labels only, 2: labels + log-probabilities) -- separate
+// instantiations, so that the 16 other launches of a forward do not carry its registers.
 // epilogue constants (bias, BN scale, BN shift) of 4 consecutive channels from the item's staged arrays
 #define H3P_EPI_READS(E, CL)                        \
     do {                                            \
@@ -389,10 +389,10 @@ constexpr int FC_TASKS = 18 * 34 * 2;
 
 }  // namespace
 
-template <int TAPS, bool G16, bool HEAD = false, int PROD = 0>
+template <int TAPS, bool G16, int HEAD = 0, int PROD = 0>
 __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptiles, int n_items, int xcd_order) {
     using SM = H3WSmem<TAPS, G16>;
-    static_assert(PROD == 0 || (TAPS == 9 && !G16 && !HEAD), "the loader-side producers belong to the 32-wide 3x3 form");
+    static_assert(PROD == 0 || (TAPS == 9 && !G16 && HEAD == 0), "the loader-side producers belong to the 32-wide 3x3 form");
     constexpr int HALO = SM::HALO, PW = SM::PW, TWW = SM::TWW, NW = SM::NW, ROWB = PW * 64, NTSTEP = SM::NTSTEP;
     // Bank swizzle of the activation tile: 16-byte slot ^= (halo column >> ASWZ) & 3.  A ds_read_b128 lane group of 16
     // lanes spans 16 consecutive-ish columns of ONE row in the 32-wide geometry (>> 2 is conflict free for all three dx)
@@ -697,8 +697,8 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
         epi[0][1 + tid / TN][tid % TN] = tid < TN ? 1.f : 0.f;
         epi[1][1 + tid / TN][tid % TN] = tid < TN ? 1.f : 0.f;
     }
-    static_assert(!HEAD || (TAPS == 9 && !G16), "the fused head belongs to the 32-wide 3x3 form");
-    if constexpr (HEAD) {
+    static_assert(HEAD == 0 || (TAPS == 9 && !G16), "the fused head belongs to the 32-wide 3x3 form");
+    if constexpr (HEAD != 0) {
         for (int i = tid; i < p.head_C * 64; i += 512) hw[i] = p.head_w[i];
         if (tid < p.head_C) hw[kMaxClasses * 64 + tid] = p.head_b[tid];
     }
@@ -808,12 +808,15 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
             const int yb = y0 + (G16 ? 4 * (wave & 3) : 2 * wave);  // first image row of the wave's N-tile 0
             const int Hp = p.H >> 1, Wp = p.W >> 1;
             const char* ep = reinterpret_cast<const char*>(&epi[epar][0][0]);
-            if constexpr (HEAD) {
+            if constexpr (HEAD != 0) {
                 // ---- fused head: this item holds ALL 64 channels of its pixels (n0 == 0).  Per pixel the two lanes kb = 0/1
-                // own channels 8q + 4kb + k (q = mg, k = 0..3).  launch_head_h3 sums each 8-channel block as one fma chain
-                // (k = 0..7 from 0) and then adds the blocks pairwise (q ^ 4, q ^ 2, q ^ 1): the chain is continued across
-                // the lane pair with one shuffle and the pairwise tree is evaluated in registers, on the values a reader of
-                // the split tensor would see (hi + lo) -- the labels are bit-identical to the unfused path.
+                // own channels 8q + 4kb + k (q = mg, k = 0..3).  The head is evaluated on the fp32 values themselves -- the last
+                // conv's output is never rounded to a 22-bit hi/lo pair on this path (round 3 did so to stay bit-identical with
+                // launch_head_h3 on the stored tensor; that kernel, which only serves widths the persistent kernel does not, is now
+                // the one that may differ on near-tie pixels) -- in launch_head_h3's summation order: each 8-channel block one fma
+                // chain (k = 0..7 from 0), continued across the lane pair with one shuffle, the blocks added pairwise (q ^ 4,
+                // q ^ 2, q ^ 1) in registers.  HEAD == 2 also writes the log-softmax of the logits (resunet.py:70): labels and
+                // log-probabilities of a forward come from the same numbers.
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     const int yl = yb + nt;
@@ -859,14 +862,13 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                             if (bn) t = fmaf(fmaxf(t, 0.f), ss[k], tt[k]);
                             v[k] = t;
                         }
-                        uint2 ph, plo;
-                        lm_split4(v[0], v[1], v[2], v[3], &ph, &plo);
-                        gmax = lm_pk_absmax_u16(lm_pk_absmax_u16(gmax, ph.x), ph.y);
-                        lm_unsplit4(ph, plo, vv[mg]);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) vv[mg][k] = v[k];
                     }
                     float best = 0.f;
                     int arg = 0;
-                    for (int c = 0; c < p.head_C; ++c) {
+                    float lgs[HEAD == 2 ? kMaxClasses : 1];
+                    auto logit = [&](int c) __attribute__((always_inline)) -> float {
                         float sq[8];
 #pragma unroll
                         for (int q = 0; q < 8; ++q) {
@@ -884,13 +886,44 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                             s1 = fmaf(vv[q][3], w4.w, s1);
                             sq[q] = s1;
                         }
-                        const float lg = (((sq[0] + sq[4]) + (sq[2] + sq[6])) + ((sq[1] + sq[5]) + (sq[3] + sq[7]))) + hw[kMaxClasses * 64 + c];
-                        if (c == 0 || lg > best) {
-                            best = lg;
-                            arg = c;
+                        return (((sq[0] + sq[4]) + (sq[2] + sq[6])) + ((sq[1] + sq[5]) + (sq[3] + sq[7]))) + hw[kMaxClasses * 64 + c];
+                    };
+                    if constexpr (HEAD == 2) {  // (unrolled: the logits stay in registers for the log-softmax)
+#pragma unroll
+                        for (int c = 0; c < kMaxClasses; ++c) {
+                            if (c < p.head_C) {  // wave-uniform
+                                const float lg = logit(c);
+                                lgs[c] = lg;
+                                if (c == 0 || lg > best) {
+                                    best = lg;
+                                    arg = c;
+                                }
+                            }
+                        }
+                    } else {
+#pragma unroll 1
+                        for (int c = 0; c < p.head_C; ++c) {
+                            const float lg = logit(c);
+                            if (c == 0 || lg > best) {
+                                best = lg;
+                                arg = c;
+                            }
                         }
                     }
                     if (tile_ok && kb == 1) p.head_labels[((size_t)bs * p.H + yl) * p.W + x0 + li] = (uint8_t)arg;
+                    if constexpr (HEAD == 2) {  // log_softmax over the classes, launch_head_h3's formula: lg - (best + log(sum exp(lg - best)))
+                        float se = 0.f;
+#pragma unroll
+                        for (int c = 0; c < kMaxClasses; ++c)
+                            if (c < p.head_C) se += expf(lgs[c] - best);
+                        const float lse = best + logf(se);
+                        if (tile_ok && kb == 1) {
+                            const size_t HW = (size_t)p.H * p.W, yx = (size_t)yl * p.W + x0 + li;
+#pragma unroll
+                            for (int c = 0; c < kMaxClasses; ++c)
+                                if (c < p.head_C) p.head_logp[((size_t)bs * p.head_C + c) * HW + yx] = lgs[c] - lse;
+                        }
+                    }
                 }
             } else {
             // Stored output, one pass per M-tile (32 of the item's 64 channels): per 4-channel group the epilogue constants are
@@ -1089,6 +1122,7 @@ static hipError_t launch_conv_h3_t(const ConvParamsH3& p, hipStream_t stream) {
             pd.out = p.out + (size_t)b0 * p.H * p.W * p.out_cstride * 4;
             if (p.pool) pd.pool = p.pool + (size_t)b0 * (p.H / 2) * (p.W / 2) * p.pool_cstride * 4;
             if (p.head_labels) pd.head_labels = p.head_labels + (size_t)b0 * p.H * p.W;
+            if (p.head_logp) pd.head_logp = p.head_logp + (size_t)b0 * p.head_C * p.H * p.W;
             if (p.fc_x) pd.fc_x = p.fc_x + (size_t)b0 * p.H * p.W;
             const int n_ptiles = g16 ? ((p.H + TH - 1) / TH) * ((pd.B + 1) / 2) : (p.W / 32) * ((p.H + TH - 1) / TH) * pd.B;
             const int n_ct = p.Cout / TN;
@@ -1099,10 +1133,12 @@ static hipError_t launch_conv_h3_t(const ConvParamsH3& p, hipStream_t stream) {
             const unsigned blocks = (unsigned)std::min(n_items, grid_cap > 0 ? std::min(grid_cap, n_cu) : n_cu);
             if (g16)
                 LM_LAUNCH((conv_igemm_h3p<TAPS, true>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
+            else if (TAPS == 9 && pd.head_labels != nullptr && pd.head_logp != nullptr)
+                LM_LAUNCH((conv_igemm_h3p<9, false, 2>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
             else if (TAPS == 9 && pd.head_labels != nullptr)
-                LM_LAUNCH((conv_igemm_h3p<9, false, true>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
+                LM_LAUNCH((conv_igemm_h3p<9, false, 1>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
             else if (TAPS == 9 && pd.fc_x != nullptr)
-                LM_LAUNCH((conv_igemm_h3p<9, false, false, 1>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
+                LM_LAUNCH((conv_igemm_h3p<9, false, 0, 1>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
             else
                 LM_LAUNCH((conv_igemm_h3p<TAPS, false>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
             const hipError_t err = hipGetLastError();
@@ -1130,6 +1166,7 @@ hipError_t launch_conv3x3_h3(const ConvParamsH3& p, hipStream_t stream) {
     if (p.fc_x != nullptr && (!conv3x3_h3_can_fuse_first(p) || !p.fc_c)) return hipErrorInvalidValue;
     if (p.head_labels != nullptr && (!conv3x3_h3_can_fuse_head(p) || p.head_C < 1 || p.head_C > kMaxClasses || !p.head_w || !p.head_b))
         return hipErrorInvalidValue;
+    if (p.head_logp != nullptr && p.head_labels == nullptr) return hipErrorInvalidValue;
     return launch_conv_h3_t<9>(p, stream);
 }
 hipError_t launch_conv1x1_h3(const ConvParamsH3& p, hipStream_t stream) { return launch_conv_h3_t<1>(p, stream); }

@@ -61,7 +61,7 @@ def test_loader_side_fusions_are_bit_identical(gpu_engine):
                     only = gpu_engine.forward(0, x, want_logp=False)[0]
                     assert np.array_equal(lab, lab0) and np.array_equal(logp, logp0) and np.array_equal(only, only0), (C, shape, mask)
     finally:
-        gpu_engine.set_fusion(7)
+        gpu_engine.set_fusion(15)
 
 
 def test_forward_batch20_vs_oracle(gpu_engine, precision):
@@ -189,17 +189,30 @@ def test_forward_work_item_orders_agree(order):
     assert np.array_equal(lab, mine)  # the order changes nothing but the schedule: bit-identical labels
 
 
-def test_fused_head_is_bit_identical_to_the_head_kernel(gpu_engine):
-    """Labels-only forwards (the production path) run the head inside the last conv's epilogue; with log-probs requested
-    the separate head kernel runs on the stored tensor.  Identical labels, also at the image border and for 6 classes."""
+def test_fused_head_labels_and_log_probabilities(gpu_engine):
+    """The head (last 1x1 conv + log-softmax + argmax, resunet.py:69-70, mask.py:184-186) runs inside the last conv's epilogue on its fp32
+    results, for labels-only forwards (the production path) AND when log-probabilities are asked for: one set of numbers.  The
+    stand-alone head kernel (lm_set_fusion without bit 3; widths the persistent kernel does not serve) reads the stored 22-bit hi/lo
+    tensor instead: its log-probabilities agree to a few 1e-6 of the logit range, its labels everywhere but on near-tie pixels."""
     rng = np.random.default_rng(21)
-    for c, shape in ((3, (3, 256, 256)), (6, (2, 256, 256)), (3, (2, 64, 96))):
-        gpu_engine.load_state_dict(0, uo.synthetic_state_dict(c))
-        x = rng.random(shape, dtype=np.float32)
-        lab_fused = gpu_engine.forward(0, x, want_logp=False)[0]
-        lab_plain, logp = gpu_engine.forward(0, x)
-        assert np.array_equal(lab_fused, lab_plain), int((lab_fused != lab_plain).sum())
-        assert np.array_equal(lab_plain, logp.argmax(1))
+    try:
+        for c, shape in ((3, (3, 256, 256)), (6, (2, 256, 256)), (3, (2, 64, 96))):
+            gpu_engine.load_state_dict(0, uo.synthetic_state_dict(c))
+            x = rng.random(shape, dtype=np.float32)
+            gpu_engine.set_fusion(15)
+            lab_only = gpu_engine.forward(0, x, want_logp=False)[0]
+            lab, logp = gpu_engine.forward(0, x)
+            assert np.array_equal(lab_only, lab) and np.array_equal(lab, logp.argmax(1))
+            gpu_engine.set_fusion(7)
+            lab_k, logp_k = gpu_engine.forward(0, x)
+            d = float(np.abs(logp - logp_k).max())
+            srt = np.sort(logp, axis=1)
+            margin = srt[:, -1] - srt[:, -2]
+            print(f"C={c} {shape}: fused head vs head kernel on the stored tensor: max|dlogp| {d:.2e}, {int((lab != lab_k).sum())} labels differ")
+            assert d < 2e-5 * max(1.0, float(np.abs(logp).max()) / 25.0)
+            assert not np.any((lab != lab_k) & (margin > 4 * d + 1e-6))
+    finally:
+        gpu_engine.set_fusion(15)
 
 
 def test_forward_heavy_tailed_weights(gpu_engine):

@@ -5,13 +5,14 @@ import numpy as np
 import pytest
 
 
-def test_result_arrays_are_the_callers_alone():
-    """mask.py:210 -- every apply() returns an array of its own.  LMInferer carves the results out of blocks it recycles, and a
-    block may only be used again once the previous result AND every view / slice taken from it are gone."""
+def test_result_arrays_are_the_callers_alone(emu_engine):
+    """mask.py:210 -- every apply() returns an array of its own.  LMInferer hands out root arrays over page-locked blocks of its pool
+    (lm_host_alloc); a block goes back to the pool from a weakref.finalize on the root, i.e. only once the result AND every view /
+    slice taken from it are gone -- no interpreter reference count is inspected (the getrefcount constant)."""
     from lungmask_amd.mask import LMInferer
+    from oracle import unet_oracle as uo
 
-    inf = LMInferer.__new__(LMInferer)  # no engine: only the result-memory bookkeeping is exercised
-    inf._blocks = []
+    inf = LMInferer(state_dict=uo.synthetic_state_dict(3), engine=emu_engine)
     a = inf._result_array((3, 4, 5))
     a[:] = 7
     addr = a.ctypes.data
@@ -29,7 +30,10 @@ def test_result_arrays_are_the_callers_alone():
     d = inf._result_array((2, 4, 5))        # another size never aliases
     assert not np.shares_memory(c, d) and not np.shares_memory(b, d)
     e, f = inf._result_array((3, 4, 5)), inf._result_array((3, 4, 5))
-    assert len({x.ctypes.data for x in (b, c, e, f)}) == 4 and len(inf._blocks) <= 2  # live results never share; two idle blocks kept at most
+    assert len({x.ctypes.data for x in (b, c, e, f)}) == 4  # live results never share
+    del b, c, d, e, f
+    gc.collect()
+    assert len(inf._pool.idle) <= 2  # two idle blocks kept at most, the others were freed
 
 
 def test_force_cpu_is_an_error_without_the_opt_in(monkeypatch):
