@@ -193,6 +193,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=96)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="split_f16", choices=["split_f16", "f32"])
+    ap.add_argument("--head", default="lunglike", choices=["lunglike", "random"],
+                    help="1x1 head of the synthetic stand-in weights: fitted so that the phantom's lungs are labelled as lungs (default; a label volume "
+                         "like production's for the 3-D post-processing), or the seeded random one of rounds 1-3")
     ap.add_argument("--post", default="slab", choices=["slab", "gathered"], help="N>1 post-processing: slab-sharded (default) or label all-gather + redundant whole-volume pass")
     ap.add_argument("--dist", default="torch", choices=["torch", "native"],
                     help="N>1 collectives: torch.distributed (backend nccl = RCCL) or the engine's own RCCL communicator behind the C ABI (lm_dist_*)")
@@ -265,7 +268,9 @@ def main():
     def load(c):
         if wd and os.path.exists(os.path.join(wd, pth[c])):
             return torch.load(os.path.join(wd, pth[c]), map_location="cpu"), "pretrained " + pth[c]
-        return uo.synthetic_state_dict(c), f"synthetic (lungmask_amd.synthetic.synthetic_state_dict({c}), seed 231)"
+        return (uo.synthetic_state_dict(c, head=args.head),
+                f"synthetic (lungmask_amd.synthetic.synthetic_state_dict({c}, head='{args.head}'), seed 231"
+                + ("; 1x1 head fitted so that the phantom's lungs are labelled as lungs, oracle/make_lunglike_head.py)" if args.head == "lunglike" else ")"))
 
     sd, weights = load(n_classes)
     eng.load_state_dict(0, sd)
@@ -332,6 +337,10 @@ def main():
     stats = eng.profile_read()
     eng.profile(False)
     post_info = eng.postprocess_info()
+    if not use_dist and rank == 0:  # what the label volume of this workload looks like (post-processing cost is data dependent)
+        fin = od.download()
+        post_info["label_histogram_final_volume"] = np.bincount(fin.ravel(), minlength=n_classes).tolist()
+        del fin
     # One extra, untimed pass with a single forward lane and events around EVERY launch: the per-stage table, and the
     # dominant kernel's duration when it has the GPU to itself (in the timed region two batches' kernels overlap on two
     # streams, which inflates per-kernel times).  Every rank runs it (the multi-GPU step contains collectives).

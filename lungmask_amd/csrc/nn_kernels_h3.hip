@@ -605,8 +605,15 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                 const int grp = r == 2 ? (tid >= 100 ? 1 : 0) : r;
                 const int py = pr_pyx[pi] & 0xff, px = pr_pyx[pi] >> 8;
                 const float* cw = fcc + pr_c0 + 8 * grp + 4 * half;  // this half-task's 4 channels: w[k] at + 64 k, bias + 576, scale + 640
+#if defined(LM_FC_ABL) && LM_FC_ABL == 1  // lab ablation: no LDS reads of the weights (timing only, results are garbage)
+                auto ldw = [&](int i) { return lm_f32x4{0.5f + i, 0.25f, -0.5f, 0.125f * i}; };
+#else
                 auto ldw = [&](int i) { return *reinterpret_cast<const lm_f32x4*>(cw + i * 64); };
+#endif
                 auto fma2 = [&](int k, const lm_f32x4& w) __attribute__((always_inline)) {  // tap k on the four channels
+#if defined(LM_FC_ABL) && LM_FC_ABL == 2  // lab ablation: no multiply-adds (timing only)
+                    if (k > 0) return;
+#endif
                     const lm_f32x2 w01 = {w[0], w[1]}, w23 = {w[2], w[3]};
                     if (k & 1) {
                         lm_pk_fma_bcast<1>(pr_a[0], pr_x[k >> 1], w01);

@@ -154,6 +154,13 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
     PostWorkspace& ws = e->post;
     PostInfo& info = e->post_info;
     info = PostInfo();
+    // LM_POST_TIMING=1: host-side timestamps of this call on stderr (where the wall time of the post-processing goes: kernels,
+    // the two read-backs, the merge replay) -- the call is preceded by a stream sync so that the forward is not counted
+    static const bool timing = [] { const char* v = getenv("LM_POST_TIMING"); return v && v[0] == '1'; }();
+    if (timing) (void)hipStreamSynchronize(s);
+    const auto t_start = std::chrono::steady_clock::now();
+    auto ms_now = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+    double t_enq1 = 0, t_sync1 = 0, t_replay = 0, t_enq2 = 0, t_sync2 = 0;
     std::vector<int> spare(spare_p, spare_p + (spare_p ? n_spare : 0));
     const size_t nb = rank_blocks(nvox);
     LM_TRY(ws.parent.reserve(nvox * 4));
@@ -228,7 +235,9 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
         LM_HIP(hipMemcpyAsync(ws.h_area.p, ws.area.p, (g_r + 1) * 4, hipMemcpyDeviceToHost, s));
         LM_HIP(hipMemcpyAsync(ws.h_labval.p, ws.labval.p, g_r + 1, hipMemcpyDeviceToHost, s));
         LM_HIP(hipMemcpyAsync(ws.h_recs.p, ws.recs.p, g_n * sizeof(BoundaryRec), hipMemcpyDeviceToHost, s));
+        t_enq1 = ms_now();
         LM_HIP(hipStreamSynchronize(s));
+        t_sync1 = ms_now();
         if (want_range && attempt == 0) {
             LM_TRY(range_flag_consume(e, range_slot, range_tripped));
             if (*range_tripped) return LM_OK;
@@ -264,6 +273,7 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
         replay_merge(R, area, lv, recs, nrec, spare, skip_below, lut, info);
         info.host_replay_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
+    t_replay = ms_now();
     LM_TRY(ws.lut.reserve(lut.size()));
     LM_HIP(hipMemcpyAsync(ws.lut.p, lut.data(), lut.size(), hipMemcpyHostToDevice, s));
     uint8_t* mapped = ws.mapped.as<uint8_t>();
@@ -296,7 +306,9 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
         LM_HIP(hipMemcpyAsync(bbox, bbox_dev, sizeof bbox, hipMemcpyDeviceToHost, s));
     }
     LM_HIP(hipMemcpyAsync(best, best_dev, sizeof best, hipMemcpyDeviceToHost, s));
+    t_enq2 = ms_now();
     LM_HIP(hipStreamSynchronize(s));
+    t_sync2 = ms_now();
     uint8_t* out = ws.out.as<uint8_t>();
     LM_HIP(hipMemsetAsync(out, 0, nvox, s));
     for (int label = 0; label < 256; ++label) keep_roots[label] = (label && best[label]) ? (int)(unsigned)(best[label] & 0xffffffffull) : -1;
@@ -334,6 +346,12 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
         }
     }
     LM_HIP(hipMemcpyAsync(lab, out, nvox, hipMemcpyDeviceToDevice, s));
+    if (timing) {
+        const double t_enq3 = ms_now();
+        (void)hipStreamSynchronize(s);
+        fprintf(stderr, "lm_postprocess: part 1 enqueued %.3f | read-back 1 done %.3f | merge replay done %.3f | part 2 enqueued %.3f | read-back 2 done %.3f | "
+                "part 3 enqueued %.3f | all done %.3f ms (%d regions, %u records)\n", t_enq1, t_sync1, t_replay, t_enq2, t_sync2, t_enq3, ms_now(), R, nrec);
+    }
     return LM_OK;
 }
 

@@ -192,7 +192,8 @@ class ShardedPipeline:
                     if stride:
                         self._all_gather(gathered, mine)
                         self.collectives += 1
-                self._slab_caps[rnd] = -(-(max(lens) + max(lens) // 4 + 256) // 1024) * 1024
+                # (monotone: alternating small and large volumes must not fall back to the exact-size exchange every other time)
+                self._slab_caps[rnd] = max(self._slab_caps.get(rnd, 0), -(-(max(lens) + max(lens) // 4 + 256) // 1024) * 1024)
             status = e.L.check(lib.lm_slab_step(e.h, gathered.data_ptr() + 4 * hdr, stride, (C.c_int64 * self.world)(*lens)), "lm_slab_step")
             rnd += 1
             if status == 1:
@@ -216,6 +217,24 @@ class ShardedPipeline:
         shard = torch.from_numpy(vol[b[self.rank] : b[self.rank + 1]]).to(self.device)
         return self.apply_shard(shard.contiguous(), n_total).cpu().numpy()
 
+    def apply_local(self, shard: np.ndarray, n_total: int, gather: bool = True):
+        """The rank-local form (config 5: 2400 slices over 8 GPUs): every rank passes ONLY its own contiguous block of slices
+        `shard` [n_r,h,w] (int16; n_r = shard_bounds(n_total, world) of this rank) -- no rank ever holds the whole input volume.
+        gather=True: returns the complete uint8 label volume [n_total,h,w] (the reference's result on every rank, one all-gather of
+        the output shards); gather=False: only this rank's [n_r,h,w] block (no output collective; host memory per rank stays 1/world)."""
+        shard = np.ascontiguousarray(shard)
+        if shard.dtype != np.int16:
+            if shard.dtype.kind not in "iu":
+                raise TypeError(f"ShardedPipeline.apply_local: integer HU volume expected, got {shard.dtype}")
+            if shard.size and (shard.min() < -32768 or shard.max() > 32767):
+                raise ValueError("ShardedPipeline.apply_local: values outside the int16 range")
+            shard = shard.astype(np.int16)
+        b = shard_bounds(int(n_total), self.world)
+        if shard.shape[0] != b[self.rank + 1] - b[self.rank]:
+            raise ValueError(f"rank {self.rank} of {self.world} owns slices [{b[self.rank]}, {b[self.rank + 1]}) of {n_total}: got {shard.shape[0]} slices")
+        out = self.apply_shard(torch.from_numpy(shard).to(self.device).contiguous(), int(n_total), gather=gather)
+        return out.cpu().numpy()
+
     def shard_buffers(self, n_total: int):
         """(bounds, bbox [maxc,4] int32, lab_all [world*maxc,oh,ow] u8, lab_loc = this rank's part of lab_all)."""
         bounds = shard_bounds(n_total, self.world)
@@ -226,9 +245,9 @@ class ShardedPipeline:
         lab_loc = lab_all[self.rank * maxc : (self.rank + 1) * maxc]
         return bounds, bbox, lab_all, lab_loc
 
-    def apply_shard(self, vol_shard: torch.Tensor, n_total: int) -> torch.Tensor:
+    def apply_shard(self, vol_shard: torch.Tensor, n_total: int, gather: bool = True) -> torch.Tensor:
         """vol_shard: this rank's contiguous slice block [n_r,h,w] int16, resident in the engine's memory
-        space.  Returns the FULL uint8 label volume [n_total,h,w] (same memory space)."""
+        space.  Returns the FULL uint8 label volume [n_total,h,w] (same memory space), or with gather=False this rank's block."""
         e, lib = self.e, self.e.L.lib
         n_r, h, w = (int(s) for s in vol_shard.shape)
         bounds, bbox, _, lab_loc = self.shard_buffers(n_total)
@@ -243,20 +262,20 @@ class ShardedPipeline:
             e.L.check(lib.lm_forward_batches_dev(e.h, self.slot, xf.data_ptr(), n_r, oh, ow, self.batch_size, lab_loc.data_ptr()), "lm_forward_batches_dev")
         if self._stream is None:
             e.sync()
-        return self.assemble(n_total, h, w)
+        return self.assemble(n_total, h, w, gather=gather)
 
-    def assemble(self, n_total: int, h: int, w: int) -> torch.Tensor:
+    def assemble(self, n_total: int, h: int, w: int, gather: bool = True) -> torch.Tensor:
         """Everything after the argmax: volume post-processing of the label shards in `shard_buffers(n_total)`, un-crop with
         the shard's bounding boxes, and the all-gather of the [n_total,h,w] result.  Safe to call on its own: it makes the
         engine's stream torch's current stream for its collectives (so they are ordered with the engine's kernels whatever
         stream the caller had current) and the result is complete when it returns."""
         with self._on_engine_stream():
-            out = self._assemble(n_total, h, w)
+            out = self._assemble(n_total, h, w, gather)
         if self._stream is not None:
             self._stream.synchronize()
         return out
 
-    def _assemble(self, n_total: int, h: int, w: int) -> torch.Tensor:
+    def _assemble(self, n_total: int, h: int, w: int, gather: bool = True) -> torch.Tensor:
         e, lib = self.e, self.e.L.lib
         bounds, bbox, lab_all, lab_loc = self.shard_buffers(n_total)
         counts = [bounds[r + 1] - bounds[r] for r in range(self.world)]
@@ -292,6 +311,8 @@ class ShardedPipeline:
         if self._stream is None:
             e.sync()
         # ---- exchange #2: output shards
+        if not gather:
+            return out_loc[:n_r]
         if self.dist is not None:
             self._all_gather(out_all.view(-1), out_loc.reshape(-1))
             if any(c != maxc for c in counts):

@@ -70,14 +70,19 @@ def state_dict_keys(n_classes: int):
     return keys
 
 
-def synthetic_state_dict(n_classes: int = 3, seed: int = 231) -> "OrderedDict[str, torch.Tensor]":
+def synthetic_state_dict(n_classes: int = 3, seed: int = 231, head: str = "random") -> "OrderedDict[str, torch.Tensor]":
     """Deterministic, non-degenerate stand-in for the pretrained .pth files
     (no network here).  Same keys/shapes/order as the
     reference state_dict so `mask.py:56` (n_classes = len(last tensor)) holds.
 
     Conv weights ~ U(-b, b) with b = sqrt(6/fan_in)/sqrt(3)... (Kaiming-uniform
     like torch's default), BN stats perturbed so BN is not the identity, head
-    scaled so that logits are O(10)."""
+    scaled so that logits are O(10).
+
+    head="lunglike" (seed 231, 3 or 6 classes): the 1x1 head is replaced by the committed ridge fit of
+    `oracle/make_lunglike_head.py` (lungmask_amd/data/lunglike_head_c*.npz), which makes the network call the HU phantom's lungs
+    lungs -- roughly: two lung-sized components (or five lobes) plus specks and ragged borders, i.e. a label volume of the kind the
+    3-D post-processing sees in production, instead of the random head's 60 % one-class volume."""
     g = torch.Generator().manual_seed(seed)
     sd = OrderedDict()
     for name, shape in state_dict_keys(n_classes):
@@ -102,6 +107,17 @@ def synthetic_state_dict(n_classes: int = 3, seed: int = 231) -> "OrderedDict[st
     # head: make logits O(10) with class-dependent offsets (argmax diversity)
     sd["last.weight"] = sd["last.weight"] * 12.0
     sd["last.bias"] = torch.linspace(-1.0, 1.0, n_classes)
+    if head == "lunglike":
+        import os
+
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", f"lunglike_head_c{n_classes}.npz")
+        if seed != 231 or not os.path.exists(path):
+            raise ValueError(f"no lung-like head for n_classes={n_classes}, seed={seed} (oracle/make_lunglike_head.py fits seed 231, 3 and 6 classes)")
+        fit = np.load(path)
+        sd["last.weight"] = torch.from_numpy(fit["weight"].astype(np.float32)).reshape(n_classes, 64, 1, 1).clone()
+        sd["last.bias"] = torch.from_numpy(fit["bias"].astype(np.float32)).clone()
+    elif head != "random":
+        raise ValueError("head must be 'random' or 'lunglike'")
     return sd
 
 

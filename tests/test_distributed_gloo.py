@@ -34,6 +34,23 @@ def _labels_and_boxes(n_total, res, hw, seed=7):
     return lab, boxes
 
 
+def _lung_tubes(n_total, res, seed=11):
+    """Two lung-like tubes (labels 1, 2) that run through every slab of the volume, with holes, plus specks of both labels and
+    of a third one: components, merges and hole fills all cross the slab faces."""
+    rng = np.random.default_rng(seed)
+    z, y, x = np.mgrid[0:n_total, 0:res, 0:res].astype(np.float32)
+    lab = np.zeros((n_total, res, res), np.uint8)
+    wob = 2.0 * np.sin(z / 37.0)
+    r2 = (0.22 * res * (0.6 + 0.4 * np.sin(np.pi * z / n_total))) ** 2
+    lab[(y - res / 2 - wob) ** 2 + (x - 0.3 * res) ** 2 < r2] = 1
+    lab[(y - res / 2 + wob) ** 2 + (x - 0.7 * res) ** 2 < r2] = 2
+    holes = rng.random(lab.shape) < 0.004
+    lab[holes & (lab > 0)] = 0
+    specks = rng.random(lab.shape) < 0.003
+    lab[specks & (lab == 0)] = rng.integers(1, 4, int((specks & (lab == 0)).sum())).astype(np.uint8)
+    return lab
+
+
 def _worker(rank, world, port, n_total, outdir, mode):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="4")
@@ -53,6 +70,18 @@ def _worker(rank, world, port, n_total, outdir, mode):
         vol = po.phantom(n_total, 96, 80, seed=3)
         pipe = ShardedPipeline(eng, slot=0, batch_size=2, resolution=(32, 32), dist=dist, device="cpu")
         np.save(os.path.join(outdir, f"out{rank}.npy"), pipe.apply(vol))  # every rank passes the whole volume, works on its block
+        # the rank-local form: only the own block of slices goes in (and, with gather=False, only the own block comes out)
+        np.save(os.path.join(outdir, f"loc{rank}.npy"), pipe.apply_local(vol[b[rank] : b[rank + 1]], n_total))
+        np.save(os.path.join(outdir, f"own{rank}.npy"), pipe.apply_local(vol[b[rank] : b[rank + 1]], n_total, gather=False))
+    elif mode == "post8":  # BASELINE config 5's split (8 x 300 slices) through the slab protocol at emulator resolution
+        lab = _lung_tubes(n_total, 32)
+        pipe = ShardedPipeline(eng, resolution=(32, 32), dist=dist, device="cpu", sharded_post=True)
+        for rep in range(2):  # second volume: the table lengths travel in the headers (3 instead of 6 collectives for them)
+            slab = torch.from_numpy(lab[b[rank] : b[rank + 1]].copy())
+            c0 = pipe.collectives
+            pipe.postprocess_slab(slab, b[rank], n_total)
+            np.save(os.path.join(outdir, f"slab{rep}_{rank}.npy"), slab.numpy())
+            np.save(os.path.join(outdir, f"counts{rep}_{rank}.npy"), np.asarray([pipe.collectives - c0]))
     else:  # everything after the argmax, on a structured label volume, in both post-processing forms
         lab, boxes = _labels_and_boxes(n_total, 32, (96, 80))
         for sharded in (True, False):
@@ -102,6 +131,9 @@ def test_two_rank_gloo_full_pipeline_matches_single_rank(emu_engine, tmp_path):
     mp.spawn(_worker, args=(world, _free_port(), n_total, str(tmp_path), "full"), nprocs=world, join=True)
     out0, out1 = np.load(tmp_path / "out0.npy"), np.load(tmp_path / "out1.npy")
     assert out0.shape == (n_total, 96, 80) and np.array_equal(out0, out1)  # every rank holds the full result
+    # rank-local input (no rank holds the whole input volume): same result; gather=False: the own block only
+    assert np.array_equal(np.load(tmp_path / "loc0.npy"), out0) and np.array_equal(np.load(tmp_path / "loc1.npy"), out0)
+    assert np.array_equal(np.concatenate([np.load(tmp_path / "own0.npy"), np.load(tmp_path / "own1.npy")]), out0)
     # single-rank reference through the same stage calls
     emu_engine.load_state_dict(0, uo.synthetic_state_dict(3))
     vol = po.phantom(n_total, 96, 80, seed=3)
@@ -136,6 +168,24 @@ def test_multi_rank_gloo_assemble_and_slab_protocol(tmp_path, world, n_total):
         assert np.array_equal(got, expect_slab), rep
     for r in range(world):
         assert np.load(tmp_path / f"counts{r}.npy").tolist() == [6, 3, 6], r
+
+
+def test_eight_rank_gloo_slab_protocol_on_the_config5_split(tmp_path):
+    """BASELINE.json configs[4] splits 2400 slices over 8 GPUs (8 x 300).  The slab-sharded post-processing with EIGHT ranks over
+    gloo on that split, at the emulator's 32 x 32 resolution: two lung-like tubes cross all seven slab faces; the result equals the
+    whole-volume oracle.  (No N > 1 hardware number exists: this is the protocol's correctness at the world size it is meant for.)"""
+    from lungmask_amd.build import build_emu
+    from oracle import prepost_oracle as po
+
+    build_emu()
+    world, n_total = 8, 2400
+    mp.spawn(_worker, args=(world, _free_port(), n_total, str(tmp_path), "post8"), nprocs=world, join=True)
+    expect = po.postprocessing_fast(_lung_tubes(n_total, 32))
+    for rep in range(2):
+        got = np.concatenate([np.load(tmp_path / f"slab{rep}_{r}.npy") for r in range(world)])
+        assert got.shape == expect.shape and np.array_equal(got, expect), rep
+    for r in range(world):
+        assert [int(np.load(tmp_path / f"counts{rep}_{r}.npy")[0]) for rep in range(2)] == [6, 3], r
 
 
 def test_native_dist_world_of_one_and_argument_checks(emu_engine):
