@@ -394,6 +394,19 @@ __device__ __forceinline__ void lm_pk_fma_bcast(lm_f32x2& acc, lm_f32x2 x, lm_f3
 #endif
 }
 
+// v_permlane32_swap_b32: a[lanes 32..63] <-> b[lanes 0..31] (gfx950).  In the conv epilogue lanes l and l + 32 hold the two 4-channel
+// halves of the same pixel's 8-channel group: after swapping (hi, lo) word by word, lane l owns all eight hi halves and lane l + 32
+// all eight lo halves -- one 16-byte store each instead of two 8-byte pieces staged through LDS.
+__device__ __forceinline__ void lm_permlane32_swap(unsigned& a, unsigned& b) {
+#ifdef LM_EMU_BUILD
+    const unsigned pa = __shfl_xor(a, 32), pb = __shfl_xor(b, 32);
+    if ((lm_emu::linear_tid() & 63) < 32) b = pa;
+    else a = pb;
+#else
+    asm("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+#endif
+}
+
 // Pins the order of the statements around it (the compiler otherwise moves matrix instructions across the hand-issued reads)
 #ifdef LM_EMU_BUILD
 #define LM_SCHED_FENCE() \

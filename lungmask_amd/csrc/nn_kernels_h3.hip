@@ -939,6 +939,13 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
             // compiler from overlapping consecutive groups: row after row it ran at ~370 cycles per group); the pooled value
             // of a group is complete as soon as both rows are, so no per-row accumulator array lives across the passes.
             // Staging: 64 pixels x (128 B + 16 B pad) per wave and pass.
+#ifndef LM_EPI_DIRECT
+#define LM_EPI_DIRECT 0
+#endif
+            // LM_EPI_DIRECT: no LDS staging -- the lane pair of a pixel exchanges halves (lm_permlane32_swap) and each lane stores
+            // 16 bytes (8 hi halves or 8 lo halves of one channel group) straight from registers: 32 bytes per pixel and store
+            // instruction instead of whole 128-byte lines, but no ds_write / ds_read / fence per group.
+            constexpr bool EPI_DIRECT = LM_EPI_DIRECT != 0;
             int yl2[2], bmask2[2];
             bool ok2[2], border2[2];
             char* obase[2];
@@ -1004,9 +1011,20 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                         uint2 ph, plo;
                         lm_split4(v[nt][0], v[nt][1], v[nt][2], v[nt][3], &ph, &plo);
                         gmax = lm_pk_absmax_u16(lm_pk_absmax_u16(gmax, ph.x), ph.y);
-                        char* d = hstage + (nt * 32 + li) * HSTR + ((cl & 31) >> 3) * 32 + (cl & 7) * 2;
-                        *reinterpret_cast<uint2_a*>(d) = ph;
-                        *reinterpret_cast<uint2_a*>(d + 16) = plo;
+                        if constexpr (EPI_DIRECT) {
+                            lm_permlane32_swap(ph.x, plo.x);
+                            lm_permlane32_swap(ph.y, plo.y);
+                            if (ok2[nt]) {
+                                const uint4 val = {ph.x, ph.y, plo.x, plo.y};  // kb = 0: the group's 8 hi halves, kb = 1: its 8 lo halves
+                                char* dst = obase[nt] + (size_t)li * p.out_cstride * 4 + mt * 128 + g4 * 32 + kb * 16;
+                                if (p.stream_out) lm_store16_stream(dst, val);
+                                else *reinterpret_cast<uint4_a*>(dst) = val;
+                            }
+                        } else {
+                            char* d = hstage + (nt * 32 + li) * HSTR + ((cl & 31) >> 3) * 32 + (cl & 7) * 2;
+                            *reinterpret_cast<uint2_a*>(d) = ph;
+                            *reinterpret_cast<uint2_a*>(d + 16) = plo;
+                        }
                         if (G16 && p.pool != nullptr) {  // both pool partners are in this N-tile: lane^16 (y+1) and lane^1 (x+1)
                             float q[4];
 #pragma unroll
@@ -1032,6 +1050,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                 LM_TRACE_SUB(5);
                 // the wave's own 64 pixels x 128 B are now in LDS (same-wave LDS ops are ordered): stream them out, a 128-byte
                 // line per pixel and pass, 16 bytes per lane
+                if constexpr (!EPI_DIRECT) {
                 lm_wave_lds_fence();
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -1044,8 +1063,23 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                     }
                 }
                 lm_wave_lds_fence();  // the staging rows are rewritten by the pooled values / the next pass
+                }
                 LM_TRACE_SUB(6);
-                if (!G16 && p.pool != nullptr) {
+                if (EPI_DIRECT && !G16 && p.pool != nullptr) {  // pooled row of this pass: the even lanes' pixel pairs, 16 bytes per lane
+                    char* prow = p.pool + ((((size_t)bs * Hp + (yb >> 1)) * Wp + (x0 >> 1)) * p.pool_cstride + p.pool_coff + n0) * 4;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        uint2 ph, plo;
+                        lm_split4(qs[g4][0], qs[g4][1], qs[g4][2], qs[g4][3], &ph, &plo);
+                        lm_permlane32_swap(ph.x, plo.x);
+                        lm_permlane32_swap(ph.y, plo.y);
+                        if ((li & 1) == 0 && bs < p.B && yb + 1 < p.H) {
+                            const uint4 val = {ph.x, ph.y, plo.x, plo.y};
+                            *reinterpret_cast<uint4_a*>(prow + (size_t)(li >> 1) * p.pool_cstride * 4 + mt * 128 + g4 * 32 + kb * 16) = val;
+                        }
+                    }
+                }
+                if (!EPI_DIRECT && !G16 && p.pool != nullptr) {
                     // The wave's pooled output of this pass is ONE row of 16 pixels x 32 channels.  It goes through the staging rows
                     // like the full-resolution output (the even lanes' 8-byte pieces straight to memory were 16 scattered stores
                     // at a 256-byte stride per wave -- ~4.7 k cycles per item in the in-kernel timeline, four layers of the network).
