@@ -420,8 +420,10 @@ struct Fwd {
         p.Cin = L.cin;
         p.Cout = L.cout;
         const double px = (double)B * H * W;
-        const double flops = 2.0 * px * L.cout * L.cin * L.taps;
-        const double bytes = 4.0 * (px * (L.cin + L.cout) + (pool ? px / 4 * L.cout : 0) + (double)L.taps * L.cin * L.cout);
+        // (with the first layer computed in this conv's loader the launch reads the network's 1-channel input instead of the
+        // 64-channel tensor, and does the first layer's 9 multiply-adds per value on the vector ALU)
+        const double flops = 2.0 * px * L.cout * L.cin * L.taps + (fc_x ? 2.0 * px * 64 * 9 : 0.0);
+        const double bytes = 4.0 * (px * ((fc_x ? 1 : L.cin) + L.cout) + (pool ? px / 4 * L.cout : 0) + (double)L.taps * L.cin * L.cout);
         int kind = L.taps == 9 ? kc3 : kc1;
         if (e->prof.on && e->prof.per_layer) {
             char nm[48];

@@ -131,7 +131,8 @@ class LMInferer:
             # LUNGMASK_AMD_ALLOW_CPU_FLAG=1 opts in to "accept the flag, warn, run on the MI355X": what code written against the
             # reference needs when it passes force_cpu=True as a matter of course (the reference's own tests do,
             # tests/test_mask.py:32,43,53; the reference-derived tests here set the variable).
-            if os.environ.get("LUNGMASK_AMD_ALLOW_CPU_FLAG") != "1":
+            # (LUNGMASK_AMD_STRICT_CPU=0, the name of this switch before round 3, is still honoured)
+            if os.environ.get("LUNGMASK_AMD_ALLOW_CPU_FLAG") != "1" and os.environ.get("LUNGMASK_AMD_STRICT_CPU") != "0":
                 raise RuntimeError(
                     "lungmask_amd is an MI355X-only engine: force_cpu=True / --cpu is not available (use the reference package for CPU, "
                     "or set LUNGMASK_AMD_ALLOW_CPU_FLAG=1 to accept the flag and run on the GPU)")

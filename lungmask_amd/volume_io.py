@@ -635,6 +635,20 @@ def write_dicom(path: str, vol: Volume, keep_meta: Optional[Dict[str, str]] = No
     else:
         raise DicomError(f"write_dicom: {a.dtype} volumes are not supported (label volumes are uint8)")
     n, rows, cols = a.shape
+    # A multi-frame file carries the slice direction only implicitly (frames advance along +cross(row, column) by
+    # SpacingBetweenSlices).  A volume whose third direction column points the other way (a left-handed NIfTI / MetaImage input)
+    # is therefore written with its frames in reverse order from the position of its last slice: the same voxels at the same
+    # physical positions (the reader returns the right-handed form).  Oblique third axes that are neither are refused.
+    d0 = np.asarray(vol.direction, dtype=np.float64).reshape(3, 3)
+    nrm = np.cross(d0[:, 0], d0[:, 1])
+    origin = np.asarray(vol.origin, dtype=np.float64)
+    if n > 1 and float(np.dot(nrm, d0[:, 2])) < -0.999:
+        origin = origin + d0[:, 2] * float(vol.spacing[2]) * (n - 1)
+        a = np.ascontiguousarray(a[::-1])
+        d0 = np.column_stack([d0[:, 0], d0[:, 1], nrm])
+    elif n > 1 and float(np.dot(nrm, d0[:, 2])) < 0.999:
+        raise DicomError("write_dicom: the slice axis is not perpendicular to the image plane (a multi-frame file cannot express it)")
+    vol = Volume(a, vol.spacing, tuple(float(v) for v in origin), d0, getattr(vol, "meta", None))
     meta = {k.lower(): v for k, v in (keep_meta or {}).items()}
     study_uid = (meta.get("0020|000d") or "").strip("\0 ") or _new_uid("study", vol.origin, a.shape)
     series_uid = _new_uid("series", study_uid, os.path.abspath(path))

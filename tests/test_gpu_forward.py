@@ -218,22 +218,26 @@ def test_fused_head_labels_and_log_probabilities(gpu_engine):
 def test_forward_heavy_tailed_weights(gpu_engine):
     """Trained weights are heavy-tailed.  The split-f16 packing scales each layer by a power of two so that the f16
     remainder (`lo`) of every weight down to 2^-14 of the layer's largest one stays a normal number: a layer whose largest
-    weight is 60x its typical ones must keep fp32-class accuracy (tolerance scaled with the logit range it produces)."""
+    weight is 60x its typical ones must keep fp32-class accuracy.  The head is calibrated per SURVEY Appendix D (every class's logit
+    map at std 8 on this input -- the recipe), so the north-star's ABSOLUTE bar applies: 1e-3, no scaling with the logit range
+    (VERDICT r03 #3)."""
     sd = uo.synthetic_state_dict(3)
     g = torch.Generator().manual_seed(5)
     for k, v in sd.items():
         if k.endswith(".weight") and v.ndim == 4 and v.shape[-1] == 3 and v.shape[1] >= 64:
             mask = torch.rand(v.shape, generator=g) < 5e-4
             sd[k] = torch.where(mask, v * 60.0, v)
-    gpu_engine.load_state_dict(0, sd)
     x = np.random.default_rng(8).random((2, 256, 256), dtype=np.float32)
+    sd = uo.calibrate_head(sd, torch.from_numpy(x[:1, None]), 8.0)
+    gpu_engine.load_state_dict(0, sd)
     lab, logp = gpu_engine.forward(0, x)
+    assert gpu_engine.model_precision(0) == "split_f16"
     ref = uo.forward(sd, torch.from_numpy(x[:, None])).numpy()
-    scale = max(1.0, float(np.abs(ref).max()) / 25.0)
     err = float(np.abs(logp - ref).max())
-    assert err < TOL * scale, (err, scale)
+    print(f"heavy-tailed weights, head std 8: log-probs {float(ref.min()):.0f}..{float(ref.max()):.0f}, max|dlogp| {err:.2e}")
+    assert err < TOL, err
     margin = np.sort(ref, axis=1)[:, -1] - np.sort(ref, axis=1)[:, -2]
-    assert not np.any((lab != ref.argmax(1)) & (margin > 2 * TOL * scale))
+    assert not np.any((lab != ref.argmax(1)) & (margin > 2 * TOL))
 
 
 @pytest.mark.parametrize("prec", ["split_f16", "f32"])
@@ -246,10 +250,9 @@ def test_logit_range_sweep(gpu_engine, prec):
     the exact value of its own graph and no implementation with another summation order can be within 1e-3 of it.  For those
     models the engine is held to what is checkable: it must be as close to the float64 evaluation as the reference is (factor
     2.5), and within 1e-3 + 2.5x the reference's own distance of the reference.
-    The exact-fp32 kernels (the fall-back of the f16 range guard) are swept too: their v_mfma_f32_32x32x2_f32 accumulation is one
-    fp32 rounding per TWO products along K <= 9216, against one per SIXTEEN on the split path (the 16 exact f16 products of an
-    instruction are summed before the accumulator is touched) -- they are the LESS accurate of the two (measured 6.4e-4 at std 8,
-    4x the reference's own noise) and get a factor of 5."""
+    The exact-fp32 kernels (the fall-back of the f16 range guard) are swept too: since round 4 they sum every 16-channel chunk into a
+    fresh accumulator that is added in chunk order (one chain of up to 4608 roundings before: 6.4e-4 at std 8, 4x the reference's
+    own noise) and measure 1.9e-4 / 7.5e-4 / 2.5e-3 -- as close to float64 as the reference; they get a factor of 1.5."""
     base = uo.synthetic_state_dict(3)
     ph = po.phantom(2, 512, 512)
     xs, _ = po.preprocess(ph, [256, 256])
@@ -273,7 +276,7 @@ def test_logit_range_sweep(gpu_engine, prec):
                   f"|engine-ref64| {err64:.2e}  |ref32-ref64| {noise:.2e}")
             if std == 8.0:
                 assert err < TOL, (std, err)
-            k = 2.5 if prec == "split_f16" else 5.0
+            k = 2.5 if prec == "split_f16" else 1.5  # (the chunked exact-fp32 kernel is as close to float64 as the reference itself)
             assert err < TOL + k * noise and err64 < max(TOL, k * noise), (std, err, err64, noise)
             margin = np.sort(ref, axis=1)[:, -1] - np.sort(ref, axis=1)[:, -2]
             assert not np.any((lab != ref.argmax(1)) & (margin > 2 * max(err, TOL)))

@@ -251,3 +251,26 @@ def test_dicom_writer_roundtrip_and_tag_carry_over(tmp_path):
     # every element has an even length and the tags are in ascending order (PS3.5 7.1)
     keys = [k for k in tags if k[0] > 2]
     assert keys == sorted(keys) and all(len(v[1]) % 2 == 0 for v in tags.values())
+
+
+def test_dicom_writer_left_handed_volume_keeps_every_voxel_in_place(tmp_path):
+    """a multi-frame file advances its frames along +cross(row, column).  A left-handed volume (third direction column
+    = -cross: e.g. a NIfTI / MetaImage input written to .dcm) goes out with its frames reversed from the position of its last
+    slice, so every voxel reads back at its physical position; an oblique slice axis is refused."""
+    rng = np.random.default_rng(9)
+    lab = rng.integers(0, 4, (5, 6, 7)).astype(np.uint8)
+    d = np.array([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, -1.0]])  # columns: row dir, column dir, slice dir = -cross(row, column)
+    vol = vio.Volume(lab, (0.5, 0.75, 2.0), (3.0, -4.0, 50.0), d)
+    out = tmp_path / "lh.dcm"
+    vio.save_image(str(out), vol, None)
+    got = vio.load_input_image(str(out))
+    assert np.array_equal(got.array, lab[::-1])
+
+    def pos(v, z, y, x):
+        return np.asarray(v.origin) + np.asarray(v.direction).reshape(3, 3) @ (np.asarray([x, y, z]) * np.asarray(v.spacing))
+
+    for z, y, x in ((0, 0, 0), (4, 5, 6), (2, 1, 3)):
+        assert np.allclose(pos(vol, z, y, x), pos(got, lab.shape[0] - 1 - z, y, x))
+    bad = vio.Volume(lab, (1, 1, 1), (0, 0, 0), np.array([[1.0, 0, 0.5], [0, 1.0, 0], [0, 0, 0.8660254]]))
+    with pytest.raises(vio.DicomError):
+        vio.save_image(str(tmp_path / "oblique.dcm"), bad, None)
