@@ -481,7 +481,7 @@ def main():
             "stages_note": "HIP-event time per kernel kind of ONE step, from the untimed single-lane pass after the timed region (in that pass the whole "
                            "volume is pre-processed on the main stream; in the timed region the tail's pre-processing runs beside the head's forward).  "
                            "There is no first_conv / head_argmax row: the first conv runs inside the loader of down_path.0's second conv and the head "
-                           "inside the last conv's epilogue (lm_set_fusion, default 15); both are part of conv3x3_igemm_h3",
+                           "inside the last conv's epilogue (lm_set_fusion, default 11); both are part of conv3x3_igemm_h3",
             "postprocessing": post_info,
         }
         if world == 1 and not args.no_cpu_baseline and not emu:

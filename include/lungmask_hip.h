@@ -190,13 +190,16 @@ int lm_apply_host(lm_engine* e, int slot, int fill_slot, const void* vol_host, i
 int lm_forward_batches_dev(lm_engine* e, int slot, const float* x_dev, int n, int h, int w, int batch_size,
                            uint8_t* labels_dev);
 int lm_set_streams(lm_engine* e, int n);
-/* Producer/consumer fusions of the split-f16 forward (default: all on = 15; A/B and test hook).
- * bit 0: down_path.0's first conv (Cin = 1, resunet.py:93-95) computed inside the loader of its second conv;
- * bit 1: the decoder's bilinear x2 (resunet.py:131-133) computed inside the loader of the block's first conv;
- * bit 2: fixed-order split-K for the 16 x 16 decoder 1x1 conv;
- * bit 3: the head (last 1x1 conv + log-softmax + argmax, resunet.py:69-70, mask.py:184-186) inside the last conv's epilogue.
- * Bits 0-2 keep the stand-alone kernels' operation order: bit-identical results.  Bit 3 evaluates the head on the last conv's fp32
- * results instead of the stored 22-bit hi/lo tensor: log-probabilities differ in the last bits, labels on near-tie pixels only. */
+/* Producer/consumer fusions of the split-f16 forward (default 11 = bits 0 and 3; A/B and test hook).
+ * bit 0: down_path.0's first conv (Cin = 1, resunet.py:93-95) computed inside the loader of its second conv -- the stand-alone
+ *        kernel's operation order: bit-identical results;
+ * bit 1: reserved (the decoder's bilinear x2, resunet.py:131-133, inside the loader of the block's first conv: ruled out by
+ *        measurement, DESIGN.md 3.6 -- setting it changes nothing);
+ * bit 2: split-K of the 16 x 16 / 32 x 32 decoder 1x1 convs (parts added in a fixed order: deterministic, last bits differ from
+ *        the single chain); measured slower than the single chain, hence off by default;
+ * bit 3: the head (last 1x1 conv + log-softmax + argmax, resunet.py:69-70, mask.py:184-186) inside the last conv's epilogue, on the
+ *        conv's fp32 results instead of the stored 22-bit hi/lo tensor: log-probabilities differ in the last bits, labels on
+ *        near-tie pixels only. */
 int lm_set_fusion(lm_engine* e, int mask);
 
 /* Per-kernel timing of the launches since the last reset (HIP events on the launching stream).

@@ -267,9 +267,10 @@ class Engine:
         self.L.check(self.L.lib.lm_set_streams(self.h, int(n)), "lm_set_streams")
 
     def set_fusion(self, mask: int):
-        """Bit 0: first conv inside conv 2's loader; bit 1: bilinear x2 inside the decoder conv's loader; bit 2: split-K 1x1 (all
-        three bit-identical to the stand-alone kernels); bit 3: head inside the last conv's epilogue (fp32 instead of the stored
-        22-bit tensor: differs in the last bits).  Default 15 (A/B and test hook)."""
+        """Bit 0: first conv inside conv 2's loader (bit-identical to the stand-alone kernel); bit 1: reserved (bilinear x2 inside the
+        decoder conv's loader: not built); bit 2: split-K of the 16 x 16 / 32 x 32 decoder 1x1 convs (fixed order, last bits differ;
+        measured slower -- off by default); bit 3: head inside the last conv's epilogue (fp32 instead of the stored 22-bit tensor:
+        last bits differ).  Default 11 (A/B and test hook)."""
         self.L.check(self.L.lib.lm_set_fusion(self.h, int(mask)), "lm_set_fusion")
 
     def forward_dev(self, slot: int, x: DeviceArray, labels: Optional[DeviceArray] = None, logp: Optional[DeviceArray] = None):

@@ -394,6 +394,7 @@ struct Fwd {
     const float* zeros = nullptr;  // Model::zeros_h3
 
     bool head_fused = false;  // set by conv() when the head ran inside the last conv's epilogue
+    NNWorkspace* ws = nullptr;
     int abl = 0;              // LM_LAB_HOOKS builds only: kernels left out by tools/bw_tail_ablation.py
 
     int conv(const ConvLayer& L, const float* in, int in_cs, int in_co, int H, int W, float* out, int out_cs, int out_co,
@@ -460,6 +461,14 @@ struct Fwd {
                 static const double lim_mb = [] { const char* v = getenv("LM_STREAM_OUT_MB"); return v ? atof(v) : 128.0; }();
                 q.stream_out = px * L.cout * 4.0 > lim_mb * 1048576.0 ? 1 : 0;
             }
+            if (L.taps == 1 && (e->fusion & 4) && ws != nullptr) {  // split-K for the decoder 1x1 convs with few, long work items
+                const int S = conv1x1_h3_ksplit(q);
+                if (S > 1) {
+                    LM_TRY(ws->kpart.reserve((size_t)S * B * H * W * L.cout * 4));
+                    q.ksplit = S;
+                    q.kpart = ws->kpart.as<float>();
+                }
+            }
             if (fc_x != nullptr) {  // the first layer runs inside this conv's loader (forward() has checked that it can)
                 q.fc_x = fc_x;
                 q.fc_c = fc_c;
@@ -516,6 +525,7 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
     static const bool defer_ok = [] { const char* v = getenv("LM_H3_DEFER_SHIFT"); return !(v && v[0] == '0'); }();
     f.defer = h3 && defer_ok;
     f.zeros = md.zeros_h3;
+    f.ws = &ws;
     if (h3 && !e->zero_page) {
         void* zp = nullptr;
         LM_HIP(hipMalloc(&zp, 512));

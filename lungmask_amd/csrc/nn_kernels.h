@@ -94,7 +94,15 @@ struct ConvParamsH3 {
     // order: bit-identical tensors).  `in` is ignored.  Needs Cin == 64, W % 32 == 0 and a deferred BatchNorm shift.
     const float* fc_x = nullptr;  // [B][H][W] f32
     const float* fc_c = nullptr;  // 704 floats: w[9][64] | bias[64] | bn_s[64]
+    // Split-K (1x1 form on the persistent kernel only): the 16 x 16 / 32 x 32 decoder 1x1 convs have 80 / 160 work items of 32 / 16
+    // sequential stages on 256 compute units.  With ksplit = S > 1 every item is cut into S items over Cin / S input channels each
+    // whose raw fp32 accumulators go to kpart[S][B][H][W][Cout]; launch_conv1x1_h3 then runs the reduction (parts added in index
+    // order, then scale, bias, split: a fixed order -- deterministic, not the unsplit kernel's single chain).
+    int ksplit = 1;
+    float* kpart = nullptr;
 };
+// the K split launch_conv1x1_h3 can use for this shape (1: none) -- the engine sizes kpart with it
+int conv1x1_h3_ksplit(const ConvParamsH3& p);
 // whether launch_conv3x3_h3 can take the first layer into its loader for this shape (else run launch_first_conv_h3 first)
 bool conv3x3_h3_can_fuse_first(const ConvParamsH3& p);
 constexpr float kF16Guard = 32768.f;  // 2^15: a factor 2 below the largest finite half

@@ -463,7 +463,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                                     : lm_make_rsrc(p.in + (size_t)p.in_coff * 4, (size_t)p.B * slice_bytes - (size_t)p.in_coff * 4);
     const lm_rsrc rsrcW = lm_make_rsrc(p.w, (size_t)TAPS * p.Cout * p.Cin * 4);
     const int tiles_x = p.W / TWW;
-    const int nchunks = p.Cin / KC;  // even (checked by the launcher)
+    const int nchunks = p.Cin / KC / ((TAPS == 1 && p.ksplit > 1) ? p.ksplit : 1);  // per item; even (checked by the launcher)
     // Conv -> ReLU -> BatchNorm for every 3x3 conv of the network, bias only for the decoder's 1x1 convs (resunet.py:93-105,
     // :131-133): a property of the instantiation, not a run-time select per value (the launcher sends anything else to the
     // simple kernel)
@@ -481,7 +481,11 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
     // every tile count of this network is a power of two: shifts instead of integer divisions on the item-switch path
     const bool pow2 = ((n_ct & (n_ct - 1)) | (tiles_x & (tiles_x - 1)) | (tiles_y & (tiles_y - 1))) == 0;
     const int sh_ct = 31 - __clz(n_ct), sh_tx = 31 - __clz(tiles_x), sh_ty = 31 - __clz(tiles_y);
-    auto decode = [&](int it, int& b, int& y0, int& x0, int& n0) -> bool {
+    // Split-K (1x1 form only, ConvParamsH3::ksplit > 1): the cout-tile index also counts the K split -- item (ks, ct, pt) sums input
+    // channels [ks, ks + 1) * Cin / ksplit and leaves its raw fp32 accumulators in kpart[ks]; splitk_reduce_h3_kernel adds the parts
+    // in fixed order.  kc = first input channel of the item's range.
+    const int ksplit = (TAPS == 1 && p.ksplit > 1) ? p.ksplit : 1;
+    auto decode = [&](int it, int& b, int& y0, int& x0, int& n0, int& kc) -> bool {
         int ct, pt;
         if (xcd_order) {
             const int x = it & 7, s = it >> 3;
@@ -490,6 +494,12 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
         } else {
             ct = it / n_ptiles;
             pt = it - ct * n_ptiles;
+        }
+        kc = 0;
+        if (TAPS == 1 && ksplit > 1) {  // (cout-tile-major order only: the launcher sees to it)
+            const int ks = ct / n_ct;
+            ct -= ks * n_ct;
+            kc = ks * (p.Cin / ksplit);
         }
         const bool valid = pt < n_ptiles;
         const int tx = pow2 ? (pt & (tiles_x - 1)) : pt % tiles_x;
@@ -539,8 +549,8 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
         }
     }
     int it = blockIdx.x;
-    int b, y0, x0, n0;
-    int nb = 0, ny0 = 0, nx0 = 0, nn0 = 0;
+    int b, y0, x0, n0, kc0 = 0;
+    int nb = 0, ny0 = 0, nx0 = 0, nn0 = 0, nkc0 = 0;
     int epar = 0;
     auto set_dma = [&](bool next_item, int b, int n0, int c0, int par, bool on, int epar_or_neg) __attribute__((always_inline)) {
         if constexpr (PROD == 1) {
@@ -698,7 +708,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
     };
 
     lm_f32x16 accm[2][2];  // [M-tile][N-tile = row]: all three products of the split scheme accumulate here
-    while (it < n_items && !decode(it, b, y0, x0, n0)) it += gridDim.x;
+    while (it < n_items && !decode(it, b, y0, x0, n0, kc0)) it += gridDim.x;
     if (it >= n_items) return;
     if (!bn && tid < 2 * TN) {  // no BatchNorm (decoder 1x1): identity constants, never overwritten
         epi[0][1 + tid / TN][tid % TN] = tid < TN ? 1.f : 0.f;
@@ -713,7 +723,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
     char* const buf0 = lds;
     char* const buf1 = lds + SUB * SM::BUF_BYTES;
     // prologue: stage 0 of the first item, all pieces at once (set_dma's buffer argument counts chunk images)
-    set_dma(false, b, n0, 0, 0, true, epar);
+    set_dma(false, b, n0, kc0, 0, true, epar);
 #pragma unroll
     for (int k = 0; k < N_SLOTS; ++k) dma_slot(k);
     if constexpr (PROD == 1) {  // the first item's chunk 0 is computed here, with nothing to run beside
@@ -726,7 +736,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
             for (int m = 0; m < 6; ++m) prod_step(S, m);
     }
     if (SUB == 2) {
-        set_dma(false, b, n0, KC, 1, true, -1);
+        set_dma(false, b, n0, kc0 + KC, 1, true, -1);
 #pragma unroll
         for (int k = 0; k < N_SLOTS; ++k) dma_slot(k);
     }
@@ -742,7 +752,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                     accm[i][j][r] = 0.f;
                 }
         int nit = it + gridDim.x;
-        while (nit < n_items && !decode(nit, nb, ny0, nx0, nn0)) nit += gridDim.x;
+        while (nit < n_items && !decode(nit, nb, ny0, nx0, nn0, nkc0)) nit += gridDim.x;
         const bool have_next = nit < n_items;
         item_voffs(nb, ny0, nx0, voffN);
         // (fused first layer) the next item's input patch: its buffer was last read while the previous item's chunk 2 ran, the
@@ -789,8 +799,8 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                 const int nxt = ((si + 1) & 1) * 2;  // first chunk image of the other stage buffer
 #pragma unroll
                 for (int sub = 0; sub < 2; ++sub) {  // stage the next two chunks (or the next item's first two) into the other buffer
-                    if (si + 1 < nstages) set_dma(false, b, n0, (2 * (si + 1) + sub) * KC, nxt + sub, true, -1);
-                    else set_dma(true, nb, nn0, sub * KC, sub, have_next, sub == 0 ? (epar ^ 1) : -1);
+                    if (si + 1 < nstages) set_dma(false, b, n0, kc0 + (2 * (si + 1) + sub) * KC, nxt + sub, true, -1);
+                    else set_dma(true, nb, nn0, nkc0 + sub * KC, sub, have_next, sub == 0 ? (epar ^ 1) : -1);
 #pragma unroll
                     for (int k = 0; k < N_SLOTS; ++k) dma_slot(k);
                 }
@@ -815,7 +825,30 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
             const int yb = y0 + (G16 ? 4 * (wave & 3) : 2 * wave);  // first image row of the wave's N-tile 0
             const int Hp = p.H >> 1, Wp = p.W >> 1;
             const char* ep = reinterpret_cast<const char*>(&epi[epar][0][0]);
-            if constexpr (HEAD != 0) {
+            bool part_done = false;
+            if constexpr (TAPS == 1) {
+                if (ksplit > 1) {
+                    // ---- split-K: this item's raw accumulators -> kpart[ks][slice][pixel][cout] (fp32, dense), 16 bytes per lane and
+                    // 4-channel quad; scale, bias and the split happen in the reduction
+                    const int ks = kc0 / (p.Cin / ksplit);
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const int yl = G16 ? yb + 2 * nt + (li >> 4) : yb + nt, xl = G16 ? wcol : x0 + li;
+                        const bool ok = bs < p.B && yl < p.H;
+                        float* dst = p.kpart + ((((size_t)ks * p.B + bs) * p.H + yl) * p.W + xl) * p.Cout + n0 + 4 * kb;
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                            for (int g4 = 0; g4 < 4; ++g4)
+                                if (ok)
+                                    *reinterpret_cast<float4*>(dst + 32 * mt + 8 * g4) =
+                                        make_float4(accm[mt][nt][4 * g4], accm[mt][nt][4 * g4 + 1], accm[mt][nt][4 * g4 + 2], accm[mt][nt][4 * g4 + 3]);
+                    }
+                    part_done = true;
+                }
+            }
+            if (part_done) {
+            } else if constexpr (HEAD != 0) {
                 // ---- fused head: this item holds ALL 64 channels of its pixels (n0 == 0).  Per pixel the two lanes kb = 0/1
                 // own channels 8q + 4kb + k (q = mg, k = 0..3).  The head is evaluated on the fp32 values themselves -- the last
                 // conv's output is never rounded to a 22-bit hi/lo pair on this path (round 3 did so to stay bit-identical with
@@ -1117,6 +1150,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
         y0 = ny0;
         x0 = nx0;
         n0 = nn0;
+        kc0 = nkc0;
 #pragma unroll
         for (int j = 0; j < SM::A_PER_WAVE; ++j) voffC[j] = voffN[j];
         epar ^= 1;
@@ -1167,8 +1201,9 @@ static hipError_t launch_conv_h3_t(const ConvParamsH3& p, hipStream_t stream) {
             if (p.fc_x) pd.fc_x = p.fc_x + (size_t)b0 * p.H * p.W;
             const int n_ptiles = g16 ? ((p.H + TH - 1) / TH) * ((pd.B + 1) / 2) : (p.W / 32) * ((p.H + TH - 1) / TH) * pd.B;
             const int n_ct = p.Cout / TN;
-            const int xcd_order = order_env >= 0 ? order_env : (n_ct >= 2 && n_ptiles >= 64 ? 1 : 0);
-            const int n_items = xcd_order ? 8 * ((n_ptiles + 7) / 8) * n_ct : n_ptiles * n_ct;
+            const int ks = (TAPS == 1 && p.ksplit > 1) ? p.ksplit : 1;  // split-K items: cout-tile-major order, ks outermost
+            const int xcd_order = ks > 1 ? 0 : (order_env >= 0 ? order_env : (n_ct >= 2 && n_ptiles >= 64 ? 1 : 0));
+            const int n_items = xcd_order ? 8 * ((n_ptiles + 7) / 8) * n_ct : n_ptiles * n_ct * ks;
             // LM_H3_GRID: lab hook, caps the number of persistent workgroups
             static const int grid_cap = [] { const char* e = getenv("LM_H3_GRID"); return e ? atoi(e) : 0; }();
             const unsigned blocks = (unsigned)std::min(n_items, grid_cap > 0 ? std::min(grid_cap, n_cu) : n_cu);
@@ -1210,7 +1245,62 @@ hipError_t launch_conv3x3_h3(const ConvParamsH3& p, hipStream_t stream) {
     if (p.head_logp != nullptr && p.head_labels == nullptr) return hipErrorInvalidValue;
     return launch_conv_h3_t<9>(p, stream);
 }
-hipError_t launch_conv1x1_h3(const ConvParamsH3& p, hipStream_t stream) { return launch_conv_h3_t<1>(p, stream); }
+// Reduction of a split-K 1x1 conv: thread = (pixel, 8-channel group); parts added in index order, then the conv epilogue of the 1x1
+// form (acc * 2^-k + bias, no ReLU / BatchNorm), the hi / lo split and the f16 range guard.
+__global__ __launch_bounds__(256) void splitk_reduce_h3_kernel(const float* __restrict__ part, int S, size_t npix, int Cout, float acc_scale,
+                                                               const float* __restrict__ bias, char* out, int out_cstride, int out_coff, unsigned* range_flag) {
+    const size_t G = (size_t)Cout >> 3, e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= npix * G) return;
+    const size_t pix = e / G;
+    const int g = (int)(e - pix * G);
+    float a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = 0.f;
+    for (int s = 0; s < S; ++s) {
+        const float4* src = reinterpret_cast<const float4*>(part + ((size_t)s * npix + pix) * Cout + 8 * g);
+        const float4 v0 = src[0], v1 = src[1];
+        if (s == 0) {
+            a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w; a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
+        } else {
+            a[0] += v0.x; a[1] += v0.y; a[2] += v0.z; a[3] += v0.w; a[4] += v1.x; a[5] += v1.y; a[6] += v1.z; a[7] += v1.w;
+        }
+    }
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = fmaf(a[k], acc_scale, bias[8 * g + k]);
+    uint2 h0, l0, h1, l1;
+    lm_split4(v[0], v[1], v[2], v[3], &h0, &l0);
+    lm_split4(v[4], v[5], v[6], v[7], &h1, &l1);
+    const unsigned gmax = lm_pk_absmax_u16(lm_pk_absmax_u16(lm_pk_absmax_u16(lm_pk_absmax_u16(0u, h0.x), h0.y), h1.x), h1.y);
+    char* dst = out + (pix * out_cstride + out_coff) * 4 + (size_t)g * 32;
+    *reinterpret_cast<uint4*>(dst) = uint4{h0.x, h0.y, h1.x, h1.y};
+    *reinterpret_cast<uint4*>(dst + 16) = uint4{l0.x, l0.y, l1.x, l1.y};
+    if (range_flag != nullptr && lm_pk_out_of_f16_guard(gmax)) atomicOr(range_flag, 1u);
+}
+
+int conv1x1_h3_ksplit(const ConvParamsH3& p) {
+    static const bool allow = [] { const char* e = getenv("LM_H3_SPLITK"); return !(e && e[0] == '0'); }();  // A/B hook
+    if (!allow || !h3_persistent_ok(p, 1) || p.pool != nullptr) return 1;
+    if ((size_t)p.B * p.H * p.W * p.in_cstride * 4 >= 0x7fffffffull) return 1;  // (a launch cut into sub-batches keeps the single chain)
+    const bool g16 = p.W == 16;
+    const int n_ptiles = g16 ? ((p.H + TH - 1) / TH) * ((p.B + 1) / 2) : (p.W / 32) * ((p.H + TH - 1) / TH) * p.B;
+    const int items = n_ptiles * (p.Cout / TN), nstages = p.Cin / (2 * KC);
+    int S = 1;
+    // as many parts as keep the item count within two rounds of the chip and leave every part an even number (>= 4) of stages
+    while (items * S * 2 <= 512 && nstages % (S * 2 * 2) == 0 && nstages / (S * 2) >= 4) S *= 2;
+    return S;
+}
+
+hipError_t launch_conv1x1_h3(const ConvParamsH3& p, hipStream_t stream) {
+    if (p.ksplit <= 1) return launch_conv_h3_t<1>(p, stream);
+    if (p.ksplit != conv1x1_h3_ksplit(p) || p.kpart == nullptr) return hipErrorInvalidValue;
+    const hipError_t err = launch_conv_h3_t<1>(p, stream);
+    if (err != hipSuccess) return err;
+    const size_t npix = (size_t)p.B * p.H * p.W, n = npix * (p.Cout >> 3);
+    LM_LAUNCH(splitk_reduce_h3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p.kpart, p.ksplit, npix, p.Cout, p.acc_scale, p.bias, p.out,
+              p.out_cstride, p.out_coff, p.range_flag);
+    return hipGetLastError();
+}
 
 // ---------------------------------------------------------------------------------------------
 // First layer (Cin = 1), fp32 arithmetic on the VALU, split output.  thread = (pixel, group of 8 output channels) with the

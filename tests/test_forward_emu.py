@@ -44,17 +44,17 @@ def test_fused_head_labels_and_log_probabilities(emu_engine, golden_dir):
         for c in (3, 6):
             emu_engine.load_state_dict(0, uo.synthetic_state_dict(c))
             x = g["rand32_x"][:1]
-            emu_engine.set_fusion(15)
+            emu_engine.set_fusion(11)
             lab_fused = emu_engine.forward(0, x, want_logp=False)[0]
             lab_plain, logp = emu_engine.forward(0, x)
             assert np.array_equal(lab_fused, lab_plain) and np.array_equal(lab_plain, logp.argmax(1))
-            emu_engine.set_fusion(7)
+            emu_engine.set_fusion(3)
             lab_k, logp_k = emu_engine.forward(0, x)
             d = float(np.abs(logp - logp_k).max())
             srt = np.sort(logp, axis=1)
             assert d < 2e-5 and not np.any((lab_plain != lab_k) & (srt[:, -1] - srt[:, -2] > 4 * d + 1e-6))
     finally:
-        emu_engine.set_fusion(15)
+        emu_engine.set_fusion(11)
 
 
 def test_first_conv_inside_the_loader_is_bit_identical(emu_engine, golden_dir):
@@ -65,12 +65,12 @@ def test_first_conv_inside_the_loader_is_bit_identical(emu_engine, golden_dir):
     emu_engine.load_state_dict(0, uo.synthetic_state_dict(3))
     x = np.concatenate([g["rand32_x"][:1].reshape(1, 32, 32)] * 2, axis=2)  # one 32 x 64 slice
     try:
-        emu_engine.set_fusion(14)  # everything but the first conv in the loader
+        emu_engine.set_fusion(10)  # the default without the first conv in the loader
         lab0, logp0 = emu_engine.forward(0, x)
-        emu_engine.set_fusion(15)
+        emu_engine.set_fusion(11)
         lab1, logp1 = emu_engine.forward(0, x)
     finally:
-        emu_engine.set_fusion(15)
+        emu_engine.set_fusion(11)
     assert np.array_equal(lab0, lab1) and np.array_equal(logp0, logp1)
 
 

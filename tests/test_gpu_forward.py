@@ -43,25 +43,37 @@ def test_forward_matches_reference_goldens(gpu_engine, golden_dir, C, precision)
 
 
 def test_loader_side_fusions_are_bit_identical(gpu_engine):
-    """lm_set_fusion: the first conv computed inside the loader of conv 2 (resunet.py:93-95), the decoder's bilinear x2 inside the loader
-    of the block's first conv (resunet.py:131-133, 144-155) and the fixed-order split-K of the 16 x 16 1x1 conv keep the operation order
-    of the stand-alone kernels: labels AND log-probabilities are the same bytes for every mask, on widths that take the persistent
-    kernel (multiples of 32), the 16-wide geometry and the fallback kernel, and batches that leave a partial last work item."""
+    """lm_set_fusion bit 0: the first conv computed inside the loader of conv 2 (resunet.py:93-95) keeps the operation order of the
+    stand-alone kernel -- labels AND log-probabilities are the same bytes with and without, on widths that take the persistent
+    kernel (multiples of 32), the 16-wide geometry and the fallback kernel, and batches that leave a partial last work item (bit 1,
+    the bilinear x2 in the decoder conv's loader, is reserved: not built).  Bit 2, the split-K of the 16 x 16 /
+    32 x 32 decoder 1x1 convs, adds its parts in a fixed order that is not the single chain's: deterministic, log-probabilities
+    within 3e-4, labels equal away from near-ties."""
     try:
         for C in (3, 6):
             gpu_engine.load_state_dict(0, uo.synthetic_state_dict(C))
-            for shape in ((3, 256, 256), (5, 64, 96), (2, 32, 32), (2, 48, 80), (3, 128, 32), (2, 16, 16)):
+            for shape in ((3, 256, 256), (5, 64, 96), (2, 32, 32), (2, 48, 80), (3, 128, 32), (2, 16, 16), (20, 256, 256)):
                 x = np.random.default_rng(shape[1] + C).random(shape, dtype=np.float32)
                 gpu_engine.set_fusion(0)
                 lab0, logp0 = gpu_engine.forward(0, x)
                 only0 = gpu_engine.forward(0, x, want_logp=False)[0]
-                for mask in (1, 2, 4, 7):
+                for mask in (1, 2, 3):
                     gpu_engine.set_fusion(mask)
                     lab, logp = gpu_engine.forward(0, x)
                     only = gpu_engine.forward(0, x, want_logp=False)[0]
                     assert np.array_equal(lab, lab0) and np.array_equal(logp, logp0) and np.array_equal(only, only0), (C, shape, mask)
+                gpu_engine.set_fusion(4)
+                lab4, logp4 = gpu_engine.forward(0, x)
+                lab4b, logp4b = gpu_engine.forward(0, x)
+                assert np.array_equal(lab4, lab4b) and np.array_equal(logp4, logp4b)  # a fixed order: run to run the same bytes
+                d = float(np.abs(logp4 - logp0).max())
+                srt = np.sort(logp0, axis=1)
+                assert d < 3e-4 * max(1.0, float(np.abs(logp0).max()) / 25.0), (C, shape, d)
+                assert not np.any((lab4 != lab0) & (srt[:, -1] - srt[:, -2] > 4 * d + 1e-6)), (C, shape)
+                if shape[0] == 20:
+                    print(f"C={C} {shape}: split-K 1x1 vs single chain: max|dlogp| {d:.2e}, {int((lab4 != lab0).sum())} labels differ")
     finally:
-        gpu_engine.set_fusion(15)
+        gpu_engine.set_fusion(11)
 
 
 def test_forward_batch20_vs_oracle(gpu_engine, precision):
@@ -199,11 +211,11 @@ def test_fused_head_labels_and_log_probabilities(gpu_engine):
         for c, shape in ((3, (3, 256, 256)), (6, (2, 256, 256)), (3, (2, 64, 96))):
             gpu_engine.load_state_dict(0, uo.synthetic_state_dict(c))
             x = rng.random(shape, dtype=np.float32)
-            gpu_engine.set_fusion(15)
+            gpu_engine.set_fusion(11)
             lab_only = gpu_engine.forward(0, x, want_logp=False)[0]
             lab, logp = gpu_engine.forward(0, x)
             assert np.array_equal(lab_only, lab) and np.array_equal(lab, logp.argmax(1))
-            gpu_engine.set_fusion(7)
+            gpu_engine.set_fusion(3)
             lab_k, logp_k = gpu_engine.forward(0, x)
             d = float(np.abs(logp - logp_k).max())
             srt = np.sort(logp, axis=1)
@@ -212,7 +224,7 @@ def test_fused_head_labels_and_log_probabilities(gpu_engine):
             assert d < 2e-5 * max(1.0, float(np.abs(logp).max()) / 25.0)
             assert not np.any((lab != lab_k) & (margin > 4 * d + 1e-6))
     finally:
-        gpu_engine.set_fusion(15)
+        gpu_engine.set_fusion(11)
 
 
 def test_forward_heavy_tailed_weights(gpu_engine):
