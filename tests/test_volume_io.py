@@ -274,3 +274,54 @@ def test_dicom_writer_left_handed_volume_keeps_every_voxel_in_place(tmp_path):
     bad = vio.Volume(lab, (1, 1, 1), (0, 0, 0), np.array([[1.0, 0, 0.5], [0, 1.0, 0], [0, 0, 0.8660254]]))
     with pytest.raises(vio.DicomError):
         vio.save_image(str(tmp_path / "oblique.dcm"), bad, None)
+
+
+_CONDA_PY = "/opt/conda/bin/python3.9"  # the interpreter oracle/make_golden.py runs the reference's utils.py under (scikit-image 0.18.3, imageio 2.9)
+
+
+def _have_imageio():
+    import subprocess
+
+    if not os.path.exists(_CONDA_PY):
+        return False
+    return subprocess.run([_CONDA_PY, "-c", "import imageio.plugins.dicom"], capture_output=True).returncode == 0
+
+
+@pytest.mark.skipif(not _have_imageio(), reason="no second interpreter with imageio's DICOM plugin in this container")
+@pytest.mark.parametrize("dtype", [np.uint8, np.int16])
+def test_dicom_writer_is_read_by_an_independent_parser(tmp_path, dtype):
+    """what write_dicom emits had only ever been read back by this repository's own parser.  imageio's DICOM plugin
+    (a pure-Python reader that shares no code with lungmask_amd.volume_io; neither SimpleITK nor pydicom exist in this image) reads
+    the multi-frame file: same voxels frame by frame, rows / columns / frames, pixel spacing (row \\ column order), slice spacing,
+    position and orientation of frame 0, transfer syntax, SOP class, and the carried-over text tags."""
+    import json
+    import subprocess
+
+    rng = np.random.default_rng(11)
+    lab = rng.integers(0, 6, (7, 24, 18)).astype(dtype)
+    if dtype == np.int16:
+        lab = (lab.astype(np.int16) * 411 - 1024).astype(np.int16)  # signed 16-bit values incl. negatives
+    vol = vio.Volume(lab, (0.7, 0.8, 2.5), (10.0, -20.5, 33.25), np.eye(3), {})
+    out = tmp_path / "mask.dcm"
+    vio.save_image(str(out), vol, {"0010|0010": "DOE^JANE", "0008|103e": "Created with lungmask", "0020|000d": "1.2.826.0.1.3680043.8.498.1"})
+    script = ("import sys, json, numpy as np, imageio\n"
+              "v = imageio.volread(sys.argv[1], 'DICOM')\n"
+              "np.save(sys.argv[2], np.asarray(v).astype(np.int64))\n"
+              "m = v.meta\n"
+              "keys = ['TransferSyntaxUID', 'SOPClassUID', 'SeriesDescription', 'PatientName', 'StudyInstanceUID', 'SliceSpacing', 'ImagePositionPatient',\n"
+              "        'ImageOrientationPatient', 'NumberOfFrames', 'Rows', 'Columns', 'PixelSpacing', 'BitsAllocated', 'PixelRepresentation', 'sampling']\n"
+              "print(json.dumps({k: (list(m[k]) if isinstance(m[k], tuple) else m[k]) for k in keys if k in m}))\n")
+    r = subprocess.run([_CONDA_PY, "-W", "ignore", "-c", script, str(out), str(tmp_path / "back.npy")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m = json.loads(r.stdout.strip().splitlines()[-1])
+    back = np.load(tmp_path / "back.npy")
+    if dtype == np.uint8:
+        back = back & 0xFF  # (imageio hands 8-bit unsigned frames out as int8; the labels are < 128 either way)
+    assert back.shape == lab.shape and np.array_equal(back, lab.astype(np.int64))
+    assert m["TransferSyntaxUID"] == "1.2.840.10008.1.2.1"
+    assert m["SOPClassUID"] == ("1.2.840.10008.5.1.4.1.1.7.2" if dtype == np.uint8 else "1.2.840.10008.5.1.4.1.1.7.3")
+    assert (m["NumberOfFrames"], m["Rows"], m["Columns"]) == (7, 24, 18)
+    assert m["BitsAllocated"] == (8 if dtype == np.uint8 else 16) and m["PixelRepresentation"] == (0 if dtype == np.uint8 else 1)
+    assert m["PixelSpacing"] == pytest.approx([0.8, 0.7]) and m["SliceSpacing"] == pytest.approx(2.5) and m["sampling"] == pytest.approx([2.5, 0.8, 0.7])
+    assert m["ImagePositionPatient"] == pytest.approx([10.0, -20.5, 33.25]) and m["ImageOrientationPatient"] == pytest.approx([1, 0, 0, 0, 1, 0])
+    assert m["PatientName"] == "DOE^JANE" and m["SeriesDescription"] == "Created with lungmask" and m["StudyInstanceUID"] == "1.2.826.0.1.3680043.8.498.1"
