@@ -73,6 +73,30 @@ def test_apply_ltrclobes_phantom_odd_shape(gpu_engine):
     run_case(gpu_engine, uo.synthetic_state_dict(6), vol, batch=20)
 
 
+@pytest.mark.parametrize("shape,batch,dtype", [
+    ((1, 512, 512), 20, np.int16),    # a single slice: the N == 1 branch of the hole fill (area_closing, utils.py:344-350)
+    ((2, 768, 640), 20, np.int16),    # larger than 512 and not square: crop_and_resize shrinks by two different factors
+    ((3, 96, 80), 20, np.int32),      # smaller than the network input: the order-1 zoom enlarges; int32 voxels
+    ((21, 128, 160), 20, np.int64),   # one slice more than a batch: a ragged one-slice batch on the second lane; int64 voxels
+    ((41, 128, 128), 20, np.int16),   # an odd number of batches with a ragged last one (cut in two halves, one per lane)
+])
+def test_apply_volume_geometries(gpu_engine, shape, batch, dtype):
+    """Whole path against the oracle over the volume geometries the reference accepts (any n, any h x w, the integer dtypes of
+    utils.preprocess): every case through run_case, i.e. forward mismatches only on near-ties, post-processing and un-crop bit-exact."""
+    vol = po.phantom(*shape, seed=shape[0] + shape[1]).astype(dtype)
+    run_case(gpu_engine, uo.synthetic_state_dict(3), vol, batch=batch)
+
+
+def test_apply_volume_with_air_only_slices(gpu_engine):
+    """Slices without any body (all -1024 HU: an empty body mask, utils.py:40-45 falls back to the whole slice) inside and at the
+    ends of a volume."""
+    vol = po.phantom(8, 256, 320, seed=77)
+    vol[0] = -1024
+    vol[4] = -1024
+    vol[7] = -2000  # below the clip range as well
+    run_case(gpu_engine, uo.synthetic_state_dict(3), vol, batch=3)
+
+
 def test_apply_without_volume_postprocessing(gpu_engine):
     sd = uo.synthetic_state_dict(3)
     gpu_engine.load_state_dict(0, sd)
