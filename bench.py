@@ -97,7 +97,7 @@ def cpu_baseline(n_sample, sd):
     t = time.perf_counter()
     po.inference(vol, predict, batch_size=1)
     dt = time.perf_counter() - t
-    return {
+    out = {
         "value": n_sample / dt,
         "unit": "slices/s",
         "cores": cores,
@@ -105,6 +105,42 @@ def cpu_baseline(n_sample, sd):
         "sample": f"{n_sample} central slices (z={z0}..{z0 + n_sample - 1}) of the 512x512x300 phantom, batch 1 (what --cpu forces), "
                   f"torch-CPU fp32 forward on {cores} threads ({t_nn[0]:.1f} s) + single-threaded scipy pre/post ({dt - t_nn[0]:.1f} s), {dt:.1f} s total",
     }
+    # Beside the CPU number: the same restated forward on THIS GPU through PyTorch-ROCm (eager fp32 NCHW, MIOpen / rocBLAS) -- what the
+    # reference runs without --cpu (mask.py:118-134, batch loop :173-187; SURVEY 8d's optional secondary baseline), network only, on
+    # 60 pre-processed slices in batches of 20.  A reported baseline like `value` above, never the thing `bench.py` measures; any
+    # failure of that stack is recorded, not raised.
+    try:
+        xs, _ = po.preprocess(vol[:60], [256, 256])
+        x = po.normalise(xs)[:, None].astype(np.float32)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        sdd = {k: v.to(dev) for k, v in sd.items()}
+
+        def loop():
+            with torch.inference_mode():
+                for b0 in range(0, len(x), 20):
+                    pred = uo.forward(sdd, torch.from_numpy(x[b0:b0 + 20]).float().to(dev))
+                    torch.max(pred, 1)[1].detach().cpu().numpy().astype(np.uint8)
+
+        t = time.perf_counter()
+        loop()
+        torch.cuda.synchronize()
+        warm = time.perf_counter() - t
+        best = None
+        for _ in range(2):
+            t = time.perf_counter()
+            loop()
+            torch.cuda.synchronize()
+            best = min(best or 1e9, time.perf_counter() - t)
+        out["same_gpu_reference_path"] = {
+            "value": round(len(x) / best, 1), "unit": "slices/s (network only)", "ms_per_batch_of_20": round(best / (len(x) / 20) * 1e3, 2),
+            "what": f"the restated UNet.forward in PyTorch {torch.__version__} eager fp32 on this GPU (MIOpen / rocBLAS), the batch loop of mask.py:173-187 "
+                    f"(batch to the device, forward, torch.max, labels to the host) over {len(x)} slices; first pass {warm:.1f} s (kernel selection); "
+                    "compare with this line's value / end_to_end_tflops, which include pre- and post-processing"}
+        del sdd
+        torch.cuda.empty_cache()
+    except Exception as e:  # noqa: BLE001 -- a baseline must not take the benchmark down
+        out["same_gpu_reference_path"] = {"error": repr(e)[:300]}
+    return out
 
 
 def _free_port():
