@@ -66,6 +66,22 @@ def build_emu(force: bool = False, verbose: bool = False) -> str:
     outdir = os.path.join(emu, "_build")
     os.makedirs(outdir, exist_ok=True)
     lib = os.path.join(outdir, "liblungmask_emu.so")
+    # Hardware fused multiply-add for the emulator's fmaf chains (the software fmaf of libm is ~2.5x slower over the whole CPU suite;
+    # both are correctly rounded, so every bit-exactness test is unaffected -- contraction stays off).  Only when THIS machine has
+    # the instructions, and a library built with another set of flags (it travels with gpurun snapshots) is rebuilt, not loaded.
+    arch = []
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_flags = next((ln for ln in f if ln.startswith("flags")), "").split()
+        if "fma" in cpu_flags and "avx2" in cpu_flags:
+            arch = ["-mfma", "-mavx2"]
+    except OSError:
+        pass
+    stamp = os.path.join(outdir, "flags.txt")
+    want = " ".join(arch)
+    have = open(stamp).read() if os.path.exists(stamp) else None
+    if have != want:
+        force = True
     extra = [os.path.join(emu, "hip_emu.h"), os.path.join(emu, "hip_emu_switch.cpp")]
     hdrs = _headers() + extra
     objs, cmds = [], []
@@ -73,10 +89,12 @@ def build_emu(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(outdir, os.path.basename(s).rsplit(".", 1)[0] + ".o")
         objs.append(obj)
         if force or _newer(obj, [s] + hdrs):
-            cmds.append(["g++", "-x", "c++", "-std=c++17", "-O2", "-ffp-contract=off", "-fopenmp", "-fPIC", "-DLM_EMU_BUILD", "-I", emu, "-I", CSRC, "-c", s, "-o", obj])
+            cmds.append(["g++", "-x", "c++", "-std=c++17", "-O2"] + arch + ["-ffp-contract=off", "-fopenmp", "-fPIC", "-DLM_EMU_BUILD", "-I", emu, "-I", CSRC, "-c", s, "-o", obj])
     _run_all(cmds, verbose)
     if cmds or not os.path.exists(lib):
         _run_all([["g++", "-shared", "-fopenmp", "-o", lib] + objs], verbose)
+        with open(stamp, "w") as f:
+            f.write(want)
     return lib
 
 
