@@ -232,7 +232,9 @@ def main():
     ap.add_argument("--head", default="lunglike", choices=["lunglike", "random"],
                     help="1x1 head of the synthetic stand-in weights: fitted so that the phantom's lungs are labelled as lungs (default; a label volume "
                          "like production's for the 3-D post-processing), or the seeded random one of rounds 1-3")
-    ap.add_argument("--post", default="slab", choices=["slab", "gathered"], help="N>1 post-processing: slab-sharded (default) or label all-gather + redundant whole-volume pass")
+    ap.add_argument("--post", default="auto", choices=["auto", "slab", "gathered"],
+                    help="N>1 post-processing: slab-sharded, or label all-gather + redundant whole-volume pass; auto (default) = the pipeline's own "
+                         "choice by world size: slab from three ranks on (profiles/r04r_slab_timing.log)")
     ap.add_argument("--dist", default="torch", choices=["torch", "native"],
                     help="N>1 collectives: torch.distributed (backend nccl = RCCL) or the engine's own RCCL communicator behind the C ABI (lm_dist_*)")
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2], help="forward lanes (2: consecutive batches overlap on two streams)")
@@ -349,7 +351,8 @@ def main():
 
         vt = torch.from_numpy(vol).to(dev)
         pipe = ShardedPipeline(eng, slot=0, batch_size=args.batch, resolution=res, dist=dist if dist is not None else group.nd, device=dev,
-                               sharded_post=args.post == "slab")
+                               sharded_post=None if args.post == "auto" else args.post == "slab")
+        args.post = "slab" if pipe.sharded_post else "gathered"  # (what the line reports)
 
         def step():
             pipe.apply_shard(vt, n_total)

@@ -6,10 +6,10 @@ slice-wise (utils.py:48-51, mask.py:173-187) -> contiguous slice blocks per rank
 weights replicated, NO collective.  The 3-D post-processing (utils.py:272-358) spans
 the whole volume; two forms:
 
-* slab-sharded (default): every rank post-processes its own slab and the slabs are tied
+* slab-sharded (default from three ranks on): every rank post-processes its own slab and the slabs are tied
   together by six small all-gathers of face planes / atom tables (`lm_slab_*`,
   csrc/slab_engine.hip) -- the voxel passes scale with 1/world;
-* gathered (`sharded_post=False`, and whenever a rank has no slice): ONE all-gather of the
+* gathered (`sharded_post=False`, the default with one or two ranks, and whenever a rank has no slice): ONE all-gather of the
   uint8 256x256 label shards (64 KiB/slice), then every rank runs the identical
   deterministic whole-volume post-processing (the serial fraction of weak scaling).
 
@@ -85,7 +85,7 @@ class ShardedPipeline:
     device: torch device that matches the engine's memory space ('cuda:<i>' or 'cpu' under emulation)."""
 
     def __init__(self, engine, slot: int = 0, batch_size: int = 20, volume_postprocessing: bool = True,
-                 resolution: Sequence[int] = (256, 256), dist=None, device="cpu", sharded_post: bool = True):
+                 resolution: Sequence[int] = (256, 256), dist=None, device="cpu", sharded_post=None):
         self.e = engine
         self.slot = slot
         self.batch_size = int(batch_size)
@@ -95,7 +95,10 @@ class ShardedPipeline:
         self.device = torch.device(device)
         self.world = dist.get_world_size() if dist is not None else 1
         self.rank = dist.get_rank() if dist is not None else 0
-        self.sharded_post = bool(sharded_post)
+        # None: by world size.  The slab protocol's fixed part (six exchanges, three host table merges: 3.7 ms per rank with two
+        # ranks of 300 slices) only pays from three ranks on -- the redundant whole-volume pass on the gathered labels costs 3.3 ms
+        # for 600 slices, 6.5 for 1200, 12.4 for 2400 against 3.7 / 4.3 / 5.4 (tools/slab_timing.py, profiles/r04r_slab_timing.log)
+        self.sharded_post = (self.world >= 3) if sharded_post is None else bool(sharded_post)
         self._buf = {}
         self._slab_caps = {}   # agreed capacity (ints) of the variable-length table exchange of every protocol round
         self.collectives = 0   # collectives issued for variable-length tables (tests / tools/slab_timing.py read it)

@@ -68,7 +68,7 @@ def _worker(rank, world, port, n_total, outdir, mode):
     if mode == "full":  # the whole sharded pipeline incl. the (emulated, slow) network
         eng.load_state_dict(0, uo.synthetic_state_dict(3))
         vol = po.phantom(n_total, 96, 80, seed=3)
-        pipe = ShardedPipeline(eng, slot=0, batch_size=2, resolution=(32, 32), dist=dist, device="cpu")
+        pipe = ShardedPipeline(eng, slot=0, batch_size=2, resolution=(32, 32), dist=dist, device="cpu", sharded_post=True)  # (two ranks default to the gathered form)
         np.save(os.path.join(outdir, f"out{rank}.npy"), pipe.apply(vol))  # every rank passes the whole volume, works on its block
         # the rank-local form: only the own block of slices goes in (and, with gather=False, only the own block comes out)
         np.save(os.path.join(outdir, f"loc{rank}.npy"), pipe.apply_local(vol[b[rank] : b[rank + 1]], n_total))
