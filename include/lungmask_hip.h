@@ -173,6 +173,12 @@ int lm_postprocess_info(lm_engine* e, int64_t info[5]);
 
 /* ---- label fusion (mask.py:228-230): res_l <- fuse(res_l, res_r); returns the spare label -- */
 int lm_fuse_dev(lm_engine* e, uint8_t* res_l_dev, const uint8_t* res_r_dev, size_t nvox, int* spare_out);
+/* The two halves of lm_fuse_dev for a volume whose slices are spread over several ranks (lungmask_amd/pipeline.py): `spare =
+ * res_l.max() + 1` (mask.py:228) is a maximum over the WHOLE volume, so every rank reports the maximum of its slab
+ * (lm_label_max_dev), the caller combines them (one small all-gather) and every rank fuses its slab with the agreed value
+ * (lm_fuse_spare_dev == mask.py:229-230). */
+int lm_label_max_dev(lm_engine* e, const uint8_t* lab_dev, size_t nvox, int* max_out);
+int lm_fuse_spare_dev(lm_engine* e, uint8_t* res_l_dev, const uint8_t* res_r_dev, size_t nvox, int spare);
 
 /* ---- the whole hot path: LMInferer.apply on a numpy volume (mask.py:212-232) ---------- */
 /* slot: model; fill_slot: fill model for the fused LTRCLobes_R231 mode or -1.

@@ -98,6 +98,8 @@ class Library:
         L.lm_slab_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         L.lm_postprocess_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.lm_fuse_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]
+        L.lm_label_max_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]
+        L.lm_fuse_spare_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         L.lm_apply_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
         L.lm_apply_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
         L.lm_profile_enable.argtypes = [C.c_void_p, C.c_int]
@@ -169,6 +171,7 @@ class Engine:
         h = C.c_void_p()
         self.L.check(self.L.lib.lm_engine_create(C.byref(h), device_id), "lm_engine_create")
         self.h = h.value
+        self.device_id = int(device_id)
 
     def close(self):
         if getattr(self, "h", None):

@@ -321,12 +321,18 @@ int lm_postprocess_info(lm_engine* e, int64_t info[5]) {
     return LM_OK;
 }
 
-int lm_fuse_dev(lm_engine* e, uint8_t* res_l_dev, const uint8_t* res_r_dev, size_t nvox, int* spare_out) {
-    if (!e || !res_l_dev || !res_r_dev) return LM_ERR_INVALID;
+// res_l.max() of mask.py:228 on the voxels this engine holds (a rank's slab: the pipeline combines the ranks' maxima)
+int lm_label_max_dev(lm_engine* e, const uint8_t* lab_dev, size_t nvox, int* max_out) {
+    if (!e || (!lab_dev && nvox) || !max_out) {
+        set_error("lm_label_max_dev: bad arguments");
+        return LM_ERR_INVALID;
+    }
+    *max_out = 0;
+    if (nvox == 0) return LM_OK;
     LM_DEVICE(e);
     LM_TRY(e->post.scalars.reserve(4096));
     unsigned* mx_dev = e->post.scalars.as<unsigned>() + 2;
-    hipError_t err = volume_max(res_l_dev, mx_dev, nvox, e->stream);
+    hipError_t err = volume_max(lab_dev, mx_dev, nvox, e->stream);
     if (err != hipSuccess) {
         set_error("volume_max failed: %s", hipGetErrorString(err));
         return LM_ERR_DEVICE;
@@ -334,12 +340,34 @@ int lm_fuse_dev(lm_engine* e, uint8_t* res_l_dev, const uint8_t* res_r_dev, size
     unsigned mx = 0;
     LM_HIP(hipMemcpyAsync(&mx, mx_dev, sizeof mx, hipMemcpyDeviceToHost, e->stream));
     LM_HIP(hipStreamSynchronize(e->stream));
-    const int spare = (int)((mx + 1) & 0xff);
-    err = fuse_labels(res_l_dev, res_r_dev, (uint8_t)spare, nvox, e->stream);
+    *max_out = (int)mx;
+    return LM_OK;
+}
+
+// mask.py:229-230 with a spare label the caller determined (multi-GPU: max over ALL ranks' slabs + 1)
+int lm_fuse_spare_dev(lm_engine* e, uint8_t* res_l_dev, const uint8_t* res_r_dev, size_t nvox, int spare) {
+    if (!e || ((!res_l_dev || !res_r_dev) && nvox) || spare < 0 || spare > 255) {
+        set_error("lm_fuse_spare_dev: bad arguments");
+        return LM_ERR_INVALID;
+    }
+    if (nvox == 0) return LM_OK;
+    LM_DEVICE(e);
+    e->prof.begin(e->stream, e->prof.kind_id("fuse_labels"), 0, (double)nvox * 3);
+    const hipError_t err = fuse_labels(res_l_dev, res_r_dev, (uint8_t)spare, nvox, e->stream);
+    e->prof.end(e->stream);
     if (err != hipSuccess) {
         set_error("fuse_labels failed: %s", hipGetErrorString(err));
         return LM_ERR_DEVICE;
     }
+    return LM_OK;
+}
+
+int lm_fuse_dev(lm_engine* e, uint8_t* res_l_dev, const uint8_t* res_r_dev, size_t nvox, int* spare_out) {
+    if (!e || !res_l_dev || !res_r_dev) return LM_ERR_INVALID;
+    int mx = 0;
+    LM_TRY(lm_label_max_dev(e, res_l_dev, nvox, &mx));
+    const int spare = (mx + 1) & 0xff;  // res_l.max() + 1 in uint8 arithmetic (mask.py:228)
+    LM_TRY(lm_fuse_spare_dev(e, res_l_dev, res_r_dev, nvox, spare));
     if (spare_out) *spare_out = spare;
     return LM_OK;
 }

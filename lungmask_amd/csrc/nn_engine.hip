@@ -89,12 +89,12 @@ void Profiler::begin(hipStream_t s, int kind, double flops, double bytes) {
         skipped = true;
         return;
     }
-    Rec r{kind, get_event(), get_event(), flops, bytes, lane};
-    (void)hipEventRecord(r.a, s);
-    if (timeline && t0 == nullptr) {
+    if (timeline && t0 == nullptr) {  // the timeline's origin lies in front of the first recorded launch
         t0 = get_event();
         (void)hipEventRecord(t0, s);
     }
+    Rec r{kind, get_event(), get_event(), flops, bytes, lane};
+    (void)hipEventRecord(r.a, s);
     recs.push_back(r);
 }
 void Profiler::end(hipStream_t s) {
@@ -102,6 +102,7 @@ void Profiler::end(hipStream_t s) {
     (void)hipEventRecord(recs.back().b, s);
 }
 void Profiler::collect() {
+    if (timeline && t0 != nullptr && !recs.empty()) (void)hipEventSynchronize(t0);
     for (Rec& r : recs) {
         (void)hipEventSynchronize(r.b);
         float ms = 0.f;
@@ -116,7 +117,6 @@ void Profiler::collect() {
             strncpy(sp.name, names[r.kind].c_str(), sizeof(sp.name) - 1);
             sp.lane = r.lane;
             float ta = 0.f;
-            (void)hipEventSynchronize(t0);
             (void)hipEventElapsedTime(&ta, t0, r.a);
             sp.start_ms = ta;
             sp.end_ms = (double)ta + ms;
@@ -140,6 +140,8 @@ void Profiler::reset() {
 }
 void Profiler::release() {
     collect();
+    if (t0 != nullptr) pool.push_back(t0);
+    t0 = nullptr;
     for (hipEvent_t e : pool) (void)hipEventDestroy(e);
     pool.clear();
 }

@@ -274,6 +274,20 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
         info.host_replay_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     t_replay = ms_now();
+    // utils.py:355 iterates `np.unique(outmask_mapped)[1:]`: it drops the SMALLEST value present -- the background 0 whenever the
+    // mapped volume has a background voxel, and otherwise (a volume in which every voxel carries a kept label) the smallest LABEL,
+    // which then does not appear in the result.  The mapped volume's non-zero count follows from the areas and the map.
+    int dropped_label = 0;
+    {
+        long long nonzero = 0;
+        int smallest = 256;
+        for (int a = 1; a <= R; ++a)
+            if (lut[a]) {
+                nonzero += area[a];
+                if (area[a] > 0) smallest = std::min<int>(smallest, lut[a]);
+            }
+        if (R > 0 && nonzero == (long long)nvox && smallest < 256) dropped_label = smallest;
+    }
     LM_TRY(ws.lut.reserve(lut.size()));
     LM_HIP(hipMemcpyAsync(ws.lut.p, lut.data(), lut.size(), hipMemcpyHostToDevice, s));
     uint8_t* mapped = ws.mapped.as<uint8_t>();
@@ -313,7 +327,7 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
     LM_HIP(hipMemsetAsync(out, 0, nvox, s));
     for (int label = 0; label < 256; ++label) keep_roots[label] = (label && best[label]) ? (int)(unsigned)(best[label] & 0xffffffffull) : -1;
     for (int label = 1; label < 256; ++label) {
-        if (!best[label]) continue;
+        if (!best[label] || label == dropped_label) continue;
         const int keep_root = keep_roots[label];
         if (N == 1) {  // skimage.morphology.area_closing(area_threshold=64): areas of whole components -> whole slice   utils.py:344-350
             LM_K(complement_of_component(parent, keep_root, ws.bg.as<uint8_t>(), nvox, s));

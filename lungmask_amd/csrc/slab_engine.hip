@@ -302,9 +302,22 @@ int merge_components(lm_engine* e, std::vector<uint8_t>& keeplut, std::vector<in
         const int L = clv[g] & 0xff, b = best[L];
         if (b < 0 || carea[g] > carea[b] || (carea[g] == carea[b] && cfirst[g] > cfirst[b])) best[L] = g;
     }
+    // utils.py:355 iterates `np.unique(outmask_mapped)[1:]`: without a single background voxel in the mapped volume the value it
+    // drops is the smallest LABEL (post_engine.hip: dropped_label).  The atoms of this table are the mapped volume's non-zero voxels.
+    long long nonzero = 0;
+    for (int g = 0; g < G; ++g)
+        if (uf.find(g) == g) nonzero += carea[g];
+    bool drop_smallest = G > 0 && nonzero == (long long)st.n_total * st.H * st.W;
     labels.clear();
     for (int L = 1; L < 256; ++L)
-        if (best[L] >= 0) labels.push_back(L);
+        if (best[L] >= 0) {
+            if (drop_smallest) {
+                drop_smallest = false;
+                best[L] = -1;
+                continue;
+            }
+            labels.push_back(L);
+        }
     keeplut.assign((size_t)t[st.rank].n + 1, 0);
     for (int a = 0; a < t[st.rank].n; ++a) {
         const int c = uf.find(base[st.rank] + a), L = clv[c] & 0xff;

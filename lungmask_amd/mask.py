@@ -50,40 +50,125 @@ def get_model(modelname: str, modelpath: Optional[str] = None):
 class _ResultPool:
     """Page-locked result blocks of one LMInferer: (address, bytes) pairs, idle ones kept for the next call.  A block is either in
     `idle` or owned by exactly one live root array (whose finalizer gives it back).  `close()` frees the idle blocks and marks the
-    pool closed; blocks still owned by live arrays are freed by their finalizers."""
+    pool closed; blocks still owned by live arrays are freed by their finalizers.
+    The pool keeps the LIBRARY alive, not the engine: a result array a caller holds on to must not pin the engine's ~5 GB of
+    device workspace -- page-locked memory is freed through `lm_host_free(NULL, p)` once the engine is gone."""
 
     def __init__(self, engine):
-        self.engine = engine
+        self.L = engine.L
+        self._engine = weakref.ref(engine)
         self.lock = threading.Lock()
         self.idle = []
         self.closed = False
         # (at interpreter exit the blocks are left to the process teardown: the HIP runtime may already be gone)
-        weakref.finalize(self, _ResultPool._free_all, engine, self.idle, self.lock).atexit = False
+        weakref.finalize(self, _ResultPool._free_all, self.L, self._engine, self.idle, self.lock).atexit = False
 
     @staticmethod
-    def _free_all(engine, idle, lock):
+    def _host_free(L, engine_ref, addr):
+        eng = engine_ref()
+        h = getattr(eng, "h", None) if eng is not None else None
+        try:
+            L.lib.lm_host_free(h, ctypes.c_void_p(addr))  # (h == NULL is allowed: include/lungmask_hip.h)
+        except Exception:
+            pass
+
+    @staticmethod
+    def _free_all(L, engine_ref, idle, lock):
         with lock:
             blocks, idle[:] = list(idle), []
         for addr, _ in blocks:
+            _ResultPool._host_free(L, engine_ref, addr)
+
+    def alloc(self, n: int):
+        """A page-locked block of n bytes, or None when the runtime has none left (after releasing the idle blocks)."""
+        eng = self._engine()
+        if eng is None or not getattr(eng, "h", None) or not hasattr(self.L.lib, "lm_host_alloc"):
+            return None
+        for attempt in range(2):
             try:
-                engine.host_free(addr)
-            except Exception:
-                pass
+                return (eng.host_alloc(n), n)
+            except _native.LMError:
+                if attempt == 0:
+                    _ResultPool._free_all(self.L, self._engine, self.idle, self.lock)  # idle blocks of other sizes
+        return None
 
     def give_back(self, blk):  # runs from a finalizer, possibly on another thread / during interpreter shutdown
         with self.lock:
             if not self.closed and len(self.idle) < 2:
                 self.idle.append(blk)
                 return
-        try:
-            self.engine.host_free(blk[0])
-        except Exception:
-            pass
+        _ResultPool._host_free(self.L, self._engine, blk[0])
 
     def close(self):
         with self.lock:
             self.closed = True
-        _ResultPool._free_all(self.engine, self.idle, self.lock)
+        _ResultPool._free_all(self.L, self._engine, self.idle, self.lock)
+
+
+class _ShardedApply:
+    """`LMInferer.apply` over several MI355X: the volume's slices in contiguous blocks, one block per GPU.
+    Two forms, both on `pipeline.ShardedPipeline`:
+      * one process, N engines (`engines`, one per device) driven by N threads, exchanges as peer copies (`InProcessGroup`);
+        every thread writes its block of the result straight into the caller's array;
+      * one process per GPU (`dist`: torch.distributed or a `NativeDist`): this process owns one engine and one block; every
+        rank calls `apply` with the same volume and gets the complete label volume, like the reference's single process."""
+
+    def __init__(self, engines, fill_slot, batch_size, volume_postprocessing, dist=None, sharded_post=None, resolution=(256, 256)):
+        from concurrent.futures import ThreadPoolExecutor
+
+        from .pipeline import InProcessGroup, ShardedPipeline
+
+        def dev(e):
+            return f"cuda:{e.device_id}" if e.L.is_gpu else "cpu"
+
+        self.engines = list(engines)
+        self.dist = dist
+        self.group = None
+        kw = dict(slot=0, batch_size=batch_size, volume_postprocessing=volume_postprocessing, fill_slot=fill_slot, sharded_post=sharded_post,
+                  resolution=resolution)
+        if dist is not None:
+            assert len(self.engines) == 1
+            self.pipes = [ShardedPipeline(self.engines[0], dist=dist, device=dev(self.engines[0]), **kw)]
+            self.pool = None
+        else:
+            self.group = InProcessGroup(len(self.engines))
+            self.pipes = [ShardedPipeline(e, dist=self.group.member(r, e), device=dev(e), **kw) for r, e in enumerate(self.engines)]
+            self.pool = ThreadPoolExecutor(max_workers=len(self.engines), thread_name_prefix="lungmask_amd-rank")
+
+    @property
+    def world(self):
+        return self.pipes[0].world
+
+    def apply(self, vol: np.ndarray, out: np.ndarray) -> np.ndarray:
+        from .pipeline import shard_bounds
+
+        n = int(vol.shape[0])
+        if self.dist is not None:
+            p = self.pipes[0]
+            b = shard_bounds(n, p.world)
+            return p.apply_local(vol[b[p.rank] : b[p.rank + 1]], n, gather=True, out=out)
+        b = shard_bounds(n, len(self.pipes))
+
+        def run(r):
+            try:
+                self.pipes[r].apply_local(vol[b[r] : b[r + 1]], n, gather=False, out=out[b[r] : b[r + 1]])
+            except BaseException:
+                self.group.abort()  # the other ranks raise BrokenBarrierError instead of waiting for this one
+                raise
+
+        futs = [self.pool.submit(run, r) for r in range(len(self.pipes))]
+        errs = [f.exception() for f in futs]  # (waits for every rank)
+        if any(e is not None for e in errs):
+            self.group.reset()
+            real = [e for e in errs if e is not None and not isinstance(e, threading.BrokenBarrierError)]
+            raise (real or [e for e in errs if e is not None])[0]
+        return out
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.shutdown(wait=True)
+            self.pool = None
+        self.pipes = []
 
 
 class LMInferer:
@@ -105,6 +190,11 @@ class LMInferer:
         state_dict=None,
         fill_state_dict=None,
         engine=None,
+        device_ids=None,
+        dist=None,
+        engines=None,
+        sharded_post=None,
+        resolution=(256, 256),
     ):
         assert modelname in MODEL_URLS, "Modelname not found. Please choose from: {}".format(MODEL_URLS.keys())  # mask.py:95-97
         if fillmodel is not None:
@@ -140,14 +230,37 @@ class LMInferer:
         # Extensions (not in the reference): `state_dict` / `fill_state_dict` = weights that are already in memory (what the
         # deprecated `apply(image, model)` shim and bench.py pass) instead of a file or download; `engine` = an existing
         # _native.Engine to load them into instead of a new one (one engine owns ~5 GB of workspace).
-        self.engine = engine if engine is not None else _native.Engine(device_id)
+        # Multi-GPU (not in the reference, which runs on one device): `device_ids=[0, 1, ...]` -- one engine per
+        # listed device inside THIS process, the volume's slices spread over them (`engines=[...]`: the same with existing engines);
+        # `dist=` -- one process per GPU: the initialised torch.distributed module or a `pipeline.NativeDist`, this process being
+        # one rank with its own `device_id`.  Either way `apply` keeps its contract: the complete label volume comes back.
+        self._own_engine = engine is None and engines is None
+        if engines is not None:
+            engs = list(engines)
+        elif device_ids is not None and len(device_ids) > 0:
+            assert dist is None, "device_ids (one process, several GPUs) and dist (one process per GPU) are alternatives"
+            engs = [_native.Engine(int(d)) for d in device_ids]
+        else:
+            engs = [engine if engine is not None else _native.Engine(device_id)]
+        self.engine = engs[0]
+        self._engines = engs
         self._pool = _ResultPool(self.engine)
-        self.engine.set_precision(precision)  # "split_f16" (default, fp32-class) or "f32" (exact fp32 matrix ops)
-        self.engine.load_state_dict(0, state_dict if state_dict is not None else get_model(self.modelname, modelpath))
-        self.fill_slot = -1
+        sd = state_dict if state_dict is not None else get_model(self.modelname, modelpath)
+        fsd = None
         if self.fillmodel is not None:  # mask.py:136-139
-            self.engine.load_state_dict(1, fill_state_dict if fill_state_dict is not None else get_model(self.fillmodel, fillmodel_path))
-            self.fill_slot = 1
+            fsd = fill_state_dict if fill_state_dict is not None else get_model(self.fillmodel, fillmodel_path)
+        self.fill_slot = 1 if fsd is not None else -1
+        for eng in engs:  # weights replicated: 110 MiB per model and GPU
+            eng.set_precision(precision)  # "split_f16" (default, fp32-class) or "f32" (exact fp32 matrix ops)
+            eng.load_state_dict(0, sd)
+            if fsd is not None:
+                eng.load_state_dict(1, fsd)
+        self._shard = None
+        if len(engs) > 1 or dist is not None:
+            self._shard = _ShardedApply(engs, self.fill_slot, batch_size, volume_postprocessing, dist=dist, sharded_post=sharded_post, resolution=resolution)
+        # mask.py:166 hard-codes the network resolution [256, 256]; only the multi-GPU form (built from the stage-level calls) can run
+        # another one -- what the CPU test-suite's emulated kernels need -- and nothing else may ask for it
+        assert tuple(resolution) == (256, 256) or self._shard is not None, "resolution is fixed at 256 x 256 (mask.py:166)"
 
     def _result_array(self, shape) -> np.ndarray:
         """A uint8 result array that is the caller's alone -- the reference's contract (mask.py:210) -- without paying for fresh
@@ -165,13 +278,36 @@ class LMInferer:
             blk = next((b for b in pool.idle if b[1] == n), None)
             if blk is not None:
                 pool.idle.remove(blk)
-        if blk is None:
-            if n == 0 or not hasattr(self.engine.L.lib, "lm_host_alloc"):
-                return np.empty(shape, dtype=np.uint8)
-            blk = (self.engine.host_alloc(n), n)
+        if blk is None and n:
+            blk = pool.alloc(n)
+        if blk is None:  # empty volume, an older library, or no page-locked memory left: an ordinary array (lm_apply_host takes either)
+            return np.empty(shape, dtype=np.uint8)
         root = np.ndarray(shape, dtype=np.uint8, buffer=(ctypes.c_uint8 * n).from_address(blk[0]))
         weakref.finalize(root, _ResultPool.give_back, pool, blk).atexit = False
         return root
+
+    def close(self):
+        """Releases the idle result blocks and the engine(s) this object created.  Results already handed out stay valid (their
+        blocks are freed when they are dropped)."""
+        if getattr(self, "_pool", None) is not None:
+            self._pool.close()
+        sh = getattr(self, "_shard", None)
+        if sh is not None:
+            sh.close()
+            self._shard = None
+        if getattr(self, "_own_engine", False) and getattr(self, "engine", None) is not None:
+            self.engine.close()
+        self._own_engine = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "_pool", None) is not None:
+                self._pool.close()
+            sh = getattr(self, "_shard", None)
+            if sh is not None:
+                sh.close()
+        except Exception:
+            pass
 
     def apply(self, image, out: Optional[np.ndarray] = None) -> np.ndarray:
         """mask.py:212-232 (+ _inference :141-210).  `image`: numpy volume [n,h,w], a `volume_io.Volume`, or a SimpleITK
@@ -204,6 +340,27 @@ class LMInferer:
             logger.info(f"Apply: {self.modelname}")
             logger.info(f"Apply: {self.fillmodel}")
             logger.info("Fusing results... this may take up to several minutes!")
+        if self._shard is not None and inimg_raw.ndim == 3 and inimg_raw.shape[0] > 0:
+            # slices spread over the GPUs.  The LPS re-orientation (mask.py:156-164, 204-208) is an index permutation: on the host
+            # here, because after it the slice axis may be another one than the axis the caller's array is split along.
+            direct = axes == (0, 1, 2) and not any(flips)
+            if direct:
+                vol = np.ascontiguousarray(inimg_raw)
+            else:
+                from . import volume_io
+
+                vol = np.ascontiguousarray(volume_io.apply_transform(inimg_raw, axes, flips))
+            res = out if (direct and out is not None) else self._result_array(vol.shape)
+            if res.dtype != np.uint8 or tuple(res.shape) != tuple(vol.shape) or not res.flags.c_contiguous:
+                raise _native.LMError("apply(out=...): need a C-contiguous uint8 array of the volume's shape")
+            res = self._shard.apply(vol, res)
+            if direct:
+                return res
+            back = volume_io.apply_transform(res, *volume_io.inverse_transform(axes, flips))
+            if out is not None:
+                out[...] = back
+                return out
+            return np.ascontiguousarray(back)
         if axes == (0, 1, 2) and not any(flips):
             if out is None and self.reuse_output:
                 if self._out is None or self._out.shape != tuple(inimg_raw.shape):

@@ -13,6 +13,13 @@ the whole volume; two forms:
   uint8 256x256 label shards (64 KiB/slice), then every rank runs the identical
   deterministic whole-volume post-processing (the serial fraction of weak scaling).
 
+The fused LTRCLobes_R231 mode (mask.py:223-232; SURVEY.md section 8e row 4, `fill_slot`) runs both networks on the rank's slice
+block, post-processes and un-crops both label shards, agrees on `spare = res_l.max() + 1` over ALL ranks (one 4-byte all-gather),
+fuses the own slab (lm_fuse_spare_dev) and runs the full-resolution post-processing in the same two forms.
+
+Besides one process per GPU there is a single-process form: `InProcessGroup` -- N engines (one per device) driven by N threads
+of this process, the exchanges as peer copies between the engines' buffers.  `LMInferer(device_ids=[...])` uses it.
+
 Each rank then un-crops its own slices and a final all-gather assembles the [n,h,w]
 result on every rank (79 MB per rank at 300 slices/rank; xGMI is point-to-point and fully
 connected inside a node, so it is single-step and per-link bound, well under a millisecond).
@@ -30,6 +37,7 @@ gloo and the engine is the test emulation.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import List, Sequence
 
 import numpy as np
@@ -80,14 +88,68 @@ class NativeDist:
         self.e.dist_destroy()
 
 
+class InProcessGroup:
+    """N ranks as N threads of ONE process (one engine per rank, normally one device per engine): the `dist` of rank r is
+    `member(r, engine_r)`.  An all-gather is a rendezvous of the ranks' threads and world x (world - 1) plain copies between the
+    engines' buffers (peer copies over xGMI when the engines sit on different devices) -- no RCCL, no torch.distributed.  The
+    host synchronises each engine's stream around the rendezvous; results are those of any other `dist`.  A rank that fails
+    breaks the barrier, so the other ranks raise instead of waiting for ever."""
+
+    def __init__(self, world: int):
+        self.world = int(world)
+        self.barrier = threading.Barrier(self.world)
+        self.slots = [None] * self.world
+
+    def member(self, rank: int, engine):
+        return _InProcessMember(self, int(rank), engine)
+
+    def abort(self):
+        self.barrier.abort()
+
+    def reset(self):
+        self.barrier.reset()
+
+
+class _InProcessMember:
+    def __init__(self, group: InProcessGroup, rank: int, engine):
+        self.g, self.rank, self.e = group, rank, engine
+
+    def get_world_size(self) -> int:
+        return self.g.world
+
+    def get_rank(self) -> int:
+        return self.rank
+
+    def all_gather_into_tensor(self, out: torch.Tensor, mine: torch.Tensor):
+        g, n = self.g, mine.numel()
+        assert out.is_contiguous() and mine.is_contiguous() and out.numel() == g.world * n
+        self.e.sync()  # this rank's contribution is complete (the engine's stream produced it)
+        g.slots[self.rank] = mine
+        g.barrier.wait()
+        flat = out.view(-1)
+        for r in range(g.world):
+            src, dst = g.slots[r].view(-1), flat[r * n : (r + 1) * n]
+            assert src.numel() == n and src.dtype == mine.dtype
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)  # (on the engine's stream when the pipeline made it torch's current stream)
+        if out.device.type == "cuda":
+            torch.cuda.current_stream(out.device).synchronize()
+        g.barrier.wait()  # nobody's `mine` is overwritten before every rank has read it
+        g.slots[self.rank] = None
+
+
 class ShardedPipeline:
-    """engine: lungmask_amd._native.Engine; dist: the torch.distributed module (initialised), a NativeDist, or None;
-    device: torch device that matches the engine's memory space ('cuda:<i>' or 'cpu' under emulation)."""
+    """engine: lungmask_amd._native.Engine; dist: the torch.distributed module (initialised), a NativeDist, an InProcessGroup
+    member, or None; device: torch device that matches the engine's memory space ('cuda:<i>' or 'cpu' under emulation);
+    fill_slot: model slot of the fill model of the fused LTRCLobes_R231 mode (mask.py:223-232), -1 = none."""
+
+    _TORCH_DTYPES = {torch.int16: 0, torch.int32: 1, torch.float32: 2, torch.float64: 3, torch.int64: 6}  # include/lungmask_hip.h: LM_I16 ...
 
     def __init__(self, engine, slot: int = 0, batch_size: int = 20, volume_postprocessing: bool = True,
-                 resolution: Sequence[int] = (256, 256), dist=None, device="cpu", sharded_post=None):
+                 resolution: Sequence[int] = (256, 256), dist=None, device="cpu", sharded_post=None, fill_slot: int = -1):
         self.e = engine
         self.slot = slot
+        self.fill_slot = int(fill_slot)
         self.batch_size = int(batch_size)
         self.volume_postprocessing = volume_postprocessing
         self.res = tuple(int(r) for r in resolution)
@@ -95,12 +157,12 @@ class ShardedPipeline:
         self.device = torch.device(device)
         self.world = dist.get_world_size() if dist is not None else 1
         self.rank = dist.get_rank() if dist is not None else 0
-        # None: by world size.  The slab protocol's fixed part (six exchanges, three host table merges: 3.7 ms per rank with two
-        # ranks of 300 slices) only pays from three ranks on -- the redundant whole-volume pass on the gathered labels costs 3.3 ms
-        # for 600 slices, 6.5 for 1200, 12.4 for 2400 against 3.7 / 4.3 / 5.4 (tools/slab_timing.py, profiles/r04r_slab_timing.log)
+        # None: by world size.  The slab protocol's fixed part (six exchanges, three host table merges) only pays from three ranks
+        # on -- below that the redundant whole-volume pass on the gathered labels is cheaper (tools/slab_timing.py)
         self.sharded_post = (self.world >= 3) if sharded_post is None else bool(sharded_post)
         self._buf = {}
-        self._slab_caps = {}   # agreed capacity (ints) of the variable-length table exchange of every protocol round
+        self._slab_caps = {}   # agreed capacity (ints) of the variable-length table exchange of every protocol round, per volume geometry
+        self._slab_key = None
         self.collectives = 0   # collectives issued for variable-length tables (tests / tools/slab_timing.py read it)
         # the engine's stream as torch's current stream (see the module docstring); None on the CPU / under emulation
         self._stream = None
@@ -134,6 +196,9 @@ class ShardedPipeline:
     def postprocess_slab(self, lab_slab: torch.Tensor, z0: int, n_total: int, spare: Sequence[int] = (), skip_below: int = 3):
         """utils.postprocessing over a volume whose slices are spread over the ranks; `lab_slab` (uint8 [n_r,h,w], n_r >= 1,
         slices [z0, z0+n_r)) is processed IN PLACE.  Protocol of include/lungmask_hip.h (lm_slab_*)."""
+        # (the agreed table capacities are remembered per volume geometry: the fused mode runs the protocol at the network's
+        # resolution and at full resolution within one volume)
+        self._slab_key = (tuple(int(v) for v in lab_slab.shape[1:]), len(spare))
         with self._on_engine_stream():
             return self._postprocess_slab(lab_slab, z0, n_total, spare, skip_below)
 
@@ -167,7 +232,7 @@ class ShardedPipeline:
                 # the previous volume needed plus a quarter -- every rank saw the same lengths, so every rank holds the same
                 # number; the first volume (and a table that outgrows the capacity, which every rank notices at the same
                 # time) exchanges the lengths first, as before.
-                cap = self._slab_caps.get(rnd, 0)
+                cap = self._slab_caps.get((self._slab_key, rnd), 0)
                 lens = lens_known = None
                 if cap > 0:
                     mine = self._tensor("slab_mine", (cap + 1,), torch.int32)
@@ -196,76 +261,94 @@ class ShardedPipeline:
                         self._all_gather(gathered, mine)
                         self.collectives += 1
                 # (monotone: alternating small and large volumes must not fall back to the exact-size exchange every other time)
-                self._slab_caps[rnd] = max(self._slab_caps.get(rnd, 0), -(-(max(lens) + max(lens) // 4 + 256) // 1024) * 1024)
+                self._slab_caps[(self._slab_key, rnd)] = max(self._slab_caps.get((self._slab_key, rnd), 0), -(-(max(lens) + max(lens) // 4 + 256) // 1024) * 1024)
             status = e.L.check(lib.lm_slab_step(e.h, gathered.data_ptr() + 4 * hdr, stride, (C.c_int64 * self.world)(*lens)), "lm_slab_step")
             rnd += 1
             if status == 1:
                 return
 
+    @staticmethod
+    def _as_volume(volume: np.ndarray, what: str) -> np.ndarray:
+        """The dtypes the engine pre-processes on the device (lm_preprocess_dev): int16 / int32 / int64 / float32 / float64."""
+        volume = np.ascontiguousarray(volume)
+        if volume.dtype not in (np.int16, np.int32, np.int64, np.float32, np.float64):
+            raise TypeError(f"ShardedPipeline.{what}: int16/int32/int64/float32/float64 volume expected, got {volume.dtype} (LMInferer.apply widens the others)")
+        return volume
+
     def apply(self, volume: np.ndarray) -> np.ndarray:
-        """Convenience form of `LMInferer.apply` for a process group: every rank passes the SAME host volume [n,h,w] (int16),
+        """Convenience form of `LMInferer.apply` for a process group: every rank passes the SAME host volume [n,h,w],
         works on its own block of slices and returns the complete uint8 label volume."""
-        volume = np.asarray(volume)
-        if volume.dtype != np.int16:
-            # this entry point shards int16 HU volumes (what DICOM / the bench phantom give); other integer types are accepted
-            # when their values fit -- never wrapped -- and everything else belongs to LMInferer.apply (float volumes, fusion
-            # with a fill model and image orientation are not part of the sharded form)
-            if volume.dtype.kind not in "iu":
-                raise TypeError(f"ShardedPipeline.apply: integer HU volume expected, got {volume.dtype} (use LMInferer.apply)")
-            if volume.size and (volume.min() < -32768 or volume.max() > 32767):
-                raise ValueError("ShardedPipeline.apply: values outside the int16 range (use LMInferer.apply)")
-        vol = np.ascontiguousarray(volume, dtype=np.int16)
+        vol = self._as_volume(volume, "apply")
         n_total = int(vol.shape[0])
         b = shard_bounds(n_total, self.world)
         shard = torch.from_numpy(vol[b[self.rank] : b[self.rank + 1]]).to(self.device)
-        return self.apply_shard(shard.contiguous(), n_total).cpu().numpy()
+        return np.array(self.apply_shard(shard.contiguous(), n_total).cpu().numpy(), copy=True)  # (never a view of a cached buffer)
 
-    def apply_local(self, shard: np.ndarray, n_total: int, gather: bool = True):
+    def apply_local(self, shard: np.ndarray, n_total: int, gather: bool = True, out: np.ndarray = None):
         """The rank-local form (config 5: 2400 slices over 8 GPUs): every rank passes ONLY its own contiguous block of slices
-        `shard` [n_r,h,w] (int16; n_r = shard_bounds(n_total, world) of this rank) -- no rank ever holds the whole input volume.
+        `shard` [n_r,h,w] (n_r = shard_bounds(n_total, world) of this rank) -- no rank ever holds the whole input volume.
         gather=True: returns the complete uint8 label volume [n_total,h,w] (the reference's result on every rank, one all-gather of
-        the output shards); gather=False: only this rank's [n_r,h,w] block (no output collective; host memory per rank stays 1/world)."""
-        shard = np.ascontiguousarray(shard)
-        if shard.dtype != np.int16:
-            if shard.dtype.kind not in "iu":
-                raise TypeError(f"ShardedPipeline.apply_local: integer HU volume expected, got {shard.dtype}")
-            if shard.size and (shard.min() < -32768 or shard.max() > 32767):
-                raise ValueError("ShardedPipeline.apply_local: values outside the int16 range")
-            shard = shard.astype(np.int16)
+        the output shards); gather=False: only this rank's [n_r,h,w] block (no output collective; host memory per rank stays 1/world).
+        `out`: an optional uint8 C-contiguous host array of the result's shape that receives it."""
+        shard = self._as_volume(shard, "apply_local")
         b = shard_bounds(int(n_total), self.world)
         if shard.shape[0] != b[self.rank + 1] - b[self.rank]:
             raise ValueError(f"rank {self.rank} of {self.world} owns slices [{b[self.rank]}, {b[self.rank + 1]}) of {n_total}: got {shard.shape[0]} slices")
-        out = self.apply_shard(torch.from_numpy(shard).to(self.device).contiguous(), int(n_total), gather=gather)
-        return out.cpu().numpy()
+        res = self.apply_shard(torch.from_numpy(shard).to(self.device).contiguous(), int(n_total), gather=gather)
+        if out is not None:
+            if out.dtype != np.uint8 or tuple(out.shape) != tuple(res.shape) or not out.flags.c_contiguous:
+                raise ValueError("apply_local(out=...): need a C-contiguous uint8 array of the result's shape")
+            torch.from_numpy(out).copy_(res)  # device -> the caller's array, no intermediate
+            return out
+        # a copy: `res` may be a view of a cached buffer that the next call overwrites (on the CPU .numpy() does not copy)
+        return np.array(res.cpu().numpy(), copy=True)
 
-    def shard_buffers(self, n_total: int):
+    def shard_buffers(self, n_total: int, key: str = "lab_all"):
         """(bounds, bbox [maxc,4] int32, lab_all [world*maxc,oh,ow] u8, lab_loc = this rank's part of lab_all)."""
         bounds = shard_bounds(n_total, self.world)
         maxc = max(bounds[r + 1] - bounds[r] for r in range(self.world))
         oh, ow = self.res
         bbox = self._tensor("bbox", (maxc, 4), torch.int32)
-        lab_all = self._tensor("lab_all", (self.world * maxc, oh, ow), torch.uint8)
+        lab_all = self._tensor(key, (self.world * maxc, oh, ow), torch.uint8)
         lab_loc = lab_all[self.rank * maxc : (self.rank + 1) * maxc]
         return bounds, bbox, lab_all, lab_loc
 
     def apply_shard(self, vol_shard: torch.Tensor, n_total: int, gather: bool = True) -> torch.Tensor:
-        """vol_shard: this rank's contiguous slice block [n_r,h,w] int16, resident in the engine's memory
-        space.  Returns the FULL uint8 label volume [n_total,h,w] (same memory space), or with gather=False this rank's block."""
+        """vol_shard: this rank's contiguous slice block [n_r,h,w] (int16/int32/int64/float32/float64), resident in the engine's
+        memory space and produced on torch's CURRENT stream.  Returns the FULL uint8 label volume [n_total,h,w] (same memory
+        space), or with gather=False this rank's block.  The result lives in a buffer of this object: valid until the next call."""
         e, lib = self.e, self.e.L.lib
         n_r, h, w = (int(s) for s in vol_shard.shape)
         bounds, bbox, _, lab_loc = self.shard_buffers(n_total)
         assert n_r == bounds[self.rank + 1] - bounds[self.rank], (n_r, bounds, self.rank)
-        assert vol_shard.dtype == torch.int16 and vol_shard.is_contiguous()
+        if vol_shard.dtype not in self._TORCH_DTYPES or not vol_shard.is_contiguous():
+            raise TypeError(f"apply_shard: contiguous int16/int32/int64/float32/float64 tensor expected, got {vol_shard.dtype}")
+        dtype = self._TORCH_DTYPES[vol_shard.dtype]
         oh, ow = self.res
         xf = self._tensor("xf", (max(n_r, 1), oh, ow), torch.float32)
-        self._sync_torch()  # the caller's shard (copied in on another stream) is complete
+        # the caller's shard is complete when its stream reaches this point: the engine's stream waits for exactly that -- an event,
+        # not a device-wide synchronisation (other engines / lanes on this device keep running)
+        if self._stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._stream.wait_event(ev)
+        else:
+            self._sync_torch()
         # ---- sliced stages: no communication
         if n_r:
-            e.L.check(lib.lm_preprocess_dev(e.h, vol_shard.data_ptr(), 0, n_r, h, w, oh, ow, bbox.data_ptr(), xf.data_ptr(), None, None), "lm_preprocess_dev")
+            e.L.check(lib.lm_preprocess_dev(e.h, vol_shard.data_ptr(), dtype, n_r, h, w, oh, ow, bbox.data_ptr(), xf.data_ptr(), None, None), "lm_preprocess_dev")
             e.L.check(lib.lm_forward_batches_dev(e.h, self.slot, xf.data_ptr(), n_r, oh, ow, self.batch_size, lab_loc.data_ptr()), "lm_forward_batches_dev")
+        if self.fill_slot < 0:
+            if self._stream is None:
+                e.sync()
+            return self.assemble(n_total, h, w, gather=gather)
+        # ---- fused mode: the fill model on the same pre-processed slices (the reference recomputes the identical pre-processing)
+        _, _, _, lab_fill = self.shard_buffers(n_total, "lab_fill")
+        if n_r:
+            e.L.check(lib.lm_forward_batches_dev(e.h, self.fill_slot, xf.data_ptr(), n_r, oh, ow, self.batch_size, lab_fill.data_ptr()), "lm_forward_batches_dev")
         if self._stream is None:
             e.sync()
-        return self.assemble(n_total, h, w, gather=gather)
+        return self.assemble_fused(n_total, h, w, gather=gather)
 
     def assemble(self, n_total: int, h: int, w: int, gather: bool = True) -> torch.Tensor:
         """Everything after the argmax: volume post-processing of the label shards in `shard_buffers(n_total)`, un-crop with
@@ -278,50 +361,127 @@ class ShardedPipeline:
             self._stream.synchronize()
         return out
 
-    def _assemble(self, n_total: int, h: int, w: int, gather: bool = True) -> torch.Tensor:
+    def assemble_fused(self, n_total: int, h: int, w: int, gather: bool = True) -> torch.Tensor:
+        """`assemble` for the fused mode: the base model's label shards in `shard_buffers(n_total)`, the fill model's in
+        `shard_buffers(n_total, "lab_fill")`."""
+        with self._on_engine_stream():
+            out = self._assemble_fused(n_total, h, w, gather)
+        if self._stream is not None:
+            self._stream.synchronize()
+        return out
+
+    def _counts(self, n_total):
+        bounds = shard_bounds(n_total, self.world)
+        return bounds, [bounds[r + 1] - bounds[r] for r in range(self.world)]
+
+    def _use_slabs(self, counts, n_total) -> bool:
+        # (a process group of ONE rank still runs the exchange protocol: that is how the RCCL calls are exercised on a 1-GPU box)
+        return bool(self.sharded_post and self.dist is not None and min(counts) >= 1 and n_total > 1)
+
+    def _compact(self, all_t: torch.Tensor, counts, maxc) -> torch.Tensor:
+        """[world * maxc, ...] with every rank's shard padded to maxc slices -> [n_total, ...]."""
+        if any(c != maxc for c in counts):
+            return torch.cat([all_t[r * maxc : r * maxc + counts[r]] for r in range(self.world)]).contiguous()
+        return all_t
+
+    def _post_lowres(self, n_total: int, key: str) -> torch.Tensor:
+        """Volume post-processing (mask.py:191-194) of the network-resolution label shards in buffer `key`; returns this rank's
+        post-processed slices [n_r,oh,ow]."""
         e, lib = self.e, self.e.L.lib
-        bounds, bbox, lab_all, lab_loc = self.shard_buffers(n_total)
-        counts = [bounds[r + 1] - bounds[r] for r in range(self.world)]
+        bounds, _, lab_all, lab_loc = self.shard_buffers(n_total, key)
+        _, counts = self._counts(n_total)
         n_r, maxc = counts[self.rank], max(counts)
         oh, ow = self.res
-        # (a process group of ONE rank still runs the exchange protocol: that is how the RCCL calls are exercised on a 1-GPU box)
-        slabs = self.sharded_post and self.dist is not None and min(counts) >= 1 and n_total > 1
-        if slabs:
+        if self._use_slabs(counts, n_total):
             # ---- post-processing on the own slab; six small exchanges inside (no label all-gather at all)
             mine_lab = lab_loc[:n_r]
             if self.volume_postprocessing:
                 self.postprocess_slab(mine_lab, bounds[self.rank], n_total)
-        else:
-            # ---- exchange #1: 256^2 label shards -> whole label volume on every rank (RCCL all-gather, in place)
-            if self.dist is not None:
+            return mine_lab
+        # ---- exchange #1: 256^2 label shards -> whole label volume on every rank (RCCL all-gather, in place)
+        if self.dist is not None:
+            if self.volume_postprocessing:  # (without the volume pass every rank only needs its own slices)
                 self._all_gather(lab_all.view(-1), lab_loc.reshape(-1))
-                if any(c != maxc for c in counts):  # ragged tail: compact the padded shards
-                    full = torch.cat([lab_all[r * maxc : r * maxc + counts[r]] for r in range(self.world)]).contiguous()
-                else:
-                    full = lab_all
+                full = self._compact(lab_all, counts, maxc)
             else:
-                full = lab_all[:n_r]
-            if self._stream is None:
-                self._sync_torch()
-            if self.volume_postprocessing and n_total:
-                e.L.check(lib.lm_postprocess_dev(e.h, full.data_ptr(), n_total, oh, ow, None, 0, 3), "lm_postprocess_dev")
-            mine_lab = full[bounds[self.rank] : bounds[self.rank + 1]]
-        # ---- un-crop own slices
-        out_all = self._tensor("out_all", (self.world * maxc, h, w), torch.uint8)
-        out_loc = out_all[self.rank * maxc : (self.rank + 1) * maxc]
-        if n_r:
-            e.L.check(lib.lm_reshape_mask_dev(e.h, mine_lab.data_ptr(), bbox.data_ptr(), n_r, oh, ow, h, w, out_loc.data_ptr()), "lm_reshape_mask_dev")
+                return lab_loc[:n_r]
+        else:
+            full = lab_all[:n_r]
+        if self._stream is None:
+            self._sync_torch()
+        if self.volume_postprocessing and n_total:
+            e.L.check(lib.lm_postprocess_dev(e.h, full.data_ptr(), n_total, oh, ow, None, 0, 3), "lm_postprocess_dev")
+        return full[bounds[self.rank] : bounds[self.rank + 1]]
+
+    def _uncrop(self, mine_lab: torch.Tensor, out_loc: torch.Tensor, n_r: int, h: int, w: int):
+        e, lib = self.e, self.e.L.lib
+        oh, ow = self.res
+        if n_r:  # (the bounding boxes of the own slices: written by the pre-processing into the "bbox" buffer)
+            e.L.check(lib.lm_reshape_mask_dev(e.h, mine_lab.data_ptr(), self._buf["bbox"].data_ptr(), n_r, oh, ow, h, w, out_loc.data_ptr()), "lm_reshape_mask_dev")
         if self._stream is None:
             e.sync()
-        # ---- exchange #2: output shards
+
+    def _gather_out(self, out_all: torch.Tensor, counts, gather: bool) -> torch.Tensor:
+        n_r, maxc = counts[self.rank], max(counts)
+        out_loc = out_all[self.rank * maxc : (self.rank + 1) * maxc]
         if not gather:
             return out_loc[:n_r]
         if self.dist is not None:
             self._all_gather(out_all.view(-1), out_loc.reshape(-1))
-            if any(c != maxc for c in counts):
-                return torch.cat([out_all[r * maxc : r * maxc + counts[r]] for r in range(self.world)]).contiguous()
-            return out_all
+            return self._compact(out_all, counts, maxc)
         return out_all[:n_r]
+
+    def _assemble(self, n_total: int, h: int, w: int, gather: bool = True) -> torch.Tensor:
+        _, counts = self._counts(n_total)
+        n_r, maxc = counts[self.rank], max(counts)
+        mine_lab = self._post_lowres(n_total, "lab_all")
+        # ---- un-crop own slices
+        out_all = self._tensor("out_all", (self.world * maxc, h, w), torch.uint8)
+        self._uncrop(mine_lab, out_all[self.rank * maxc : (self.rank + 1) * maxc], n_r, h, w)
+        # ---- exchange #2: output shards
+        return self._gather_out(out_all, counts, gather)
+
+    def _assemble_fused(self, n_total: int, h: int, w: int, gather: bool = True) -> torch.Tensor:
+        """mask.py:223-232 on slice blocks: res_l / res_r = post-processed + un-cropped labels of the two models on the own slab;
+        spare = max over ALL slabs + 1; fusion on the own slab; full-resolution post-processing with the spare label."""
+        e, lib = self.e, self.e.L.lib
+        bounds, counts = self._counts(n_total)
+        n_r, maxc = counts[self.rank], max(counts)
+        out_all = self._tensor("out_all", (self.world * maxc, h, w), torch.uint8)
+        out_loc = out_all[self.rank * maxc : (self.rank + 1) * maxc]
+        res_r = self._tensor("res_r", (max(n_r, 1), h, w), torch.uint8)
+        self._uncrop(self._post_lowres(n_total, "lab_all"), out_loc, n_r, h, w)   # res_l (mask.py:222)
+        self._uncrop(self._post_lowres(n_total, "lab_fill"), res_r, n_r, h, w)     # res_r (mask.py:227)
+        # ---- spare = res_l.max() + 1 over the whole volume (mask.py:228): every rank's maximum, one 4-byte all-gather
+        mx = C.c_int(0)
+        e.L.check(lib.lm_label_max_dev(e.h, out_loc.data_ptr(), n_r * h * w, C.byref(mx)), "lm_label_max_dev")
+        top = mx.value
+        if self.dist is not None and self.world > 1:
+            mine = self._tensor("mx_mine", (1,), torch.int32)
+            mx_all = self._tensor("mx_all", (self.world,), torch.int32)
+            mine.fill_(top)
+            self._all_gather(mx_all, mine)
+            top = max(int(v) for v in mx_all.cpu().tolist())
+        spare = (top + 1) & 0xff  # uint8 arithmetic, as the reference's numpy expression
+        e.L.check(lib.lm_fuse_spare_dev(e.h, out_loc.data_ptr(), res_r.data_ptr(), n_r * h * w, spare), "lm_fuse_spare_dev")  # mask.py:229-230
+        # ---- postprocessing(res_l, spare=[spare]) at full resolution (mask.py:232; not conditional on volume_postprocessing)
+        if self._use_slabs(counts, n_total):
+            self.postprocess_slab(out_loc[:n_r], bounds[self.rank], n_total, spare=(spare,))
+            return self._gather_out(out_all, counts, gather)
+        if self.dist is not None:
+            self._all_gather(out_all.view(-1), out_loc.reshape(-1))
+            full = self._compact(out_all, counts, maxc)
+        else:
+            full = out_all[:n_r]
+        if self._stream is None:
+            self._sync_torch()
+        if n_total:
+            sp = (C.c_int * 1)(spare)
+            e.L.check(lib.lm_postprocess_dev(e.h, full.data_ptr(), n_total, h, w, sp, 1, 3), "lm_postprocess_dev")
+        if self._stream is None:
+            e.sync()
+        # every rank now holds the complete result: no output collective in this form
+        return full if gather else full[bounds[self.rank] : bounds[self.rank + 1]]
 
 
 def postprocess_slabs_in_process(engines, lab: np.ndarray, bounds: Sequence[int], spare: Sequence[int] = (), skip_below: int = 3) -> np.ndarray:

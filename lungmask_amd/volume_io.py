@@ -638,17 +638,28 @@ def write_dicom(path: str, vol: Volume, keep_meta: Optional[Dict[str, str]] = No
     # A multi-frame file carries the slice direction only implicitly (frames advance along +cross(row, column) by
     # SpacingBetweenSlices).  A volume whose third direction column points the other way (a left-handed NIfTI / MetaImage input)
     # is therefore written with its frames in reverse order from the position of its last slice: the same voxels at the same
-    # physical positions (the reader returns the right-handed form).  Oblique third axes that are neither are refused.
+    # physical positions (the reader returns the right-handed form).
     d0 = np.asarray(vol.direction, dtype=np.float64).reshape(3, 3)
     nrm = np.cross(d0[:, 0], d0[:, 1])
     origin = np.asarray(vol.origin, dtype=np.float64)
-    if n > 1 and float(np.dot(nrm, d0[:, 2])) < -0.999:
-        origin = origin + d0[:, 2] * float(vol.spacing[2]) * (n - 1)
+    spacing = tuple(float(v) for v in vol.spacing)
+    cosz = float(np.dot(nrm, d0[:, 2])) if n > 1 else 1.0
+    if cosz < 0:
+        origin = origin + d0[:, 2] * spacing[2] * (n - 1)
         a = np.ascontiguousarray(a[::-1])
-        d0 = np.column_stack([d0[:, 0], d0[:, 1], nrm])
-    elif n > 1 and float(np.dot(nrm, d0[:, 2])) < 0.999:
-        raise DicomError("write_dicom: the slice axis is not perpendicular to the image plane (a multi-frame file cannot express it)")
-    vol = Volume(a, vol.spacing, tuple(float(v) for v in origin), d0, getattr(vol, "meta", None))
+        cosz = -cosz
+    if cosz < 0.999:
+        # a gantry-tilted or sheared series (`read_dicom_series` takes the slice direction from the first-to-last slice position):
+        # the file format cannot say so.  The reference's SimpleITK writer accepts such images, and this runs AFTER the whole
+        # inference: the frames are written along the in-plane normal with the slice distance projected onto it,
+        # with a warning, instead of raising and losing the result.
+        import warnings as _w
+
+        _w.warn("write_dicom: the slice axis is not perpendicular to the image plane (%.1f degrees off); a multi-frame file cannot express "
+                "that -- writing the frames along the in-plane normal with the projected spacing" % np.degrees(np.arccos(min(1.0, cosz))), RuntimeWarning)
+        spacing = (spacing[0], spacing[1], spacing[2] * cosz)
+    d0 = np.column_stack([d0[:, 0], d0[:, 1], nrm])
+    vol = Volume(a, spacing, tuple(float(v) for v in origin), d0, getattr(vol, "meta", None))
     meta = {k.lower(): v for k, v in (keep_meta or {}).items()}
     study_uid = (meta.get("0020|000d") or "").strip("\0 ") or _new_uid("study", vol.origin, a.shape)
     series_uid = _new_uid("series", study_uid, os.path.abspath(path))

@@ -132,6 +132,18 @@ def make_prepost():
     # single slice volume (area_closing path)
     ss = random_blobs(rng, (1, 64, 64), 3, 12, 0.3)
     post.append((ss, [], 3))
+    # volumes WITHOUT a background voxel: `np.unique(outmask_mapped)[1:]` (utils.py:355) then drops the smallest LABEL, not the 0
+    # (own generator: the draws of the cases below stay what they were)
+    rng_nb = np.random.default_rng(78)
+    nb = random_blobs(rng_nb, (6, 24, 24), 3, 14, 0.4)
+    nb[nb == 0] = 1
+    post += [(nb, [], 3), (nb, [3], 3)]
+    nb2 = random_blobs(rng_nb, (5, 20, 28), 2, 9, 0.4)
+    nb2[nb2 == 0] = 2
+    post.append((nb2, [], 3))
+    nb1 = random_blobs(rng_nb, (1, 40, 40), 3, 10, 0.4)
+    nb1[nb1 == 0] = 3
+    post.append((nb1, [], 3))
     inp["n_post"] = len(post)
     for i, (lab, spare, skip) in enumerate(post):
         inp[f"post{i}_lab"] = lab

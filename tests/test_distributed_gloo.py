@@ -34,6 +34,20 @@ def _labels_and_boxes(n_total, res, hw, seed=7):
     return lab, boxes
 
 
+def _fused_labels_and_boxes(n_total, seed=19):
+    """Label shards of a base model (labels 1..5 -- the TOP label only occurs in the last slices, so `res_l.max()` differs between
+    the ranks' slabs) and of a fill model (labels 1..2), with per-slice bounding boxes."""
+    from oracle.make_golden import random_blobs
+
+    rng = np.random.default_rng(seed)
+    lab_l = random_blobs(rng, (n_total, 32, 32), 4, 9, 0.3)
+    lab_l[-2:, :8, :8] = 0
+    lab_l[-1, 2:6, 2:6] = 5  # an isolated block: nothing merges into it, it merges into nothing
+    lab_r = random_blobs(rng, (n_total, 32, 32), 2, 7, 0.35)
+    _, boxes = _labels_and_boxes(n_total, 32, (96, 80), seed=seed + 1)
+    return lab_l, lab_r, boxes
+
+
 def _lung_tubes(n_total, res, seed=11):
     """Two lung-like tubes (labels 1, 2) that run through every slab of the volume, with holes, plus specks of both labels and
     of a third one: components, merges and hole fills all cross the slab faces."""
@@ -82,6 +96,19 @@ def _worker(rank, world, port, n_total, outdir, mode):
             pipe.postprocess_slab(slab, b[rank], n_total)
             np.save(os.path.join(outdir, f"slab{rep}_{rank}.npy"), slab.numpy())
             np.save(os.path.join(outdir, f"counts{rep}_{rank}.npy"), np.asarray([pipe.collectives - c0]))
+    elif mode == "fused":  # mask.py:223-232 over slice blocks: both models' label shards -> post, un-crop, spare over all ranks, fusion, full-res post
+        lab_l, lab_r, boxes = _fused_labels_and_boxes(n_total)
+        for sharded in (True, False):
+            pipe = ShardedPipeline(eng, resolution=(32, 32), dist=dist, device="cpu", sharded_post=sharded, fill_slot=1)
+            n_r = b[rank + 1] - b[rank]
+            for key, lab in (("lab_all", lab_l), ("lab_fill", lab_r)):
+                _, bbox, _, loc = pipe.shard_buffers(n_total, key)
+                loc[:n_r] = torch.from_numpy(lab[b[rank] : b[rank + 1]])
+            bbox[:n_r] = torch.from_numpy(boxes[b[rank] : b[rank + 1]])
+            np.save(os.path.join(outdir, f"fused{int(sharded)}_{rank}.npy"), pipe.assemble_fused(n_total, 96, 80).numpy().copy())
+            for key, lab in (("lab_all", lab_l), ("lab_fill", lab_r)):  # (the first run post-processed the shards in place)
+                pipe.shard_buffers(n_total, key)[3][:n_r] = torch.from_numpy(lab[b[rank] : b[rank + 1]])
+            np.save(os.path.join(outdir, f"fusedown{int(sharded)}_{rank}.npy"), pipe.assemble_fused(n_total, 96, 80, gather=False).numpy().copy())
     else:  # everything after the argmax, on a structured label volume, in both post-processing forms
         lab, boxes = _labels_and_boxes(n_total, 32, (96, 80))
         for sharded in (True, False):
@@ -226,3 +253,134 @@ def test_native_dist_world_of_one_and_argument_checks(emu_engine):
         nd.destroy()
     with pytest.raises(nat.LMError):
         emu_engine.dist_all_gather(0, 0, 16)
+
+
+@pytest.mark.parametrize("world,n_total", [(2, 5), (4, 6)])
+def test_multi_rank_gloo_fused_mode(tmp_path, world, n_total):
+    """SURVEY 8e row 4 -- the fused LTRCLobes_R231 mode (mask.py:223-232) on slice blocks with 2 and 4 ranks over gloo, ragged
+    blocks, both post-processing forms: res_l / res_r post-processed and un-cropped per rank, `spare = res_l.max() + 1` agreed over
+    all ranks (the top label only exists in the last rank's slab), fusion per slab, full-resolution post-processing with the
+    spare label.  Equals oracle.prepost_oracle.fuse on the whole volume."""
+    from lungmask_amd.build import build_emu
+    from lungmask_amd.pipeline import shard_bounds
+    from oracle import prepost_oracle as po
+
+    build_emu()
+    mp.spawn(_worker, args=(world, _free_port(), n_total, str(tmp_path), "fused"), nprocs=world, join=True)
+    lab_l, lab_r, boxes = _fused_labels_and_boxes(n_total)
+
+    def one(lab):
+        post = po.postprocessing(lab.copy())
+        return np.asarray([po.reshape_mask(post[i], boxes[i], (96, 80)) for i in range(n_total)], dtype=np.uint8)
+
+    res_l = one(lab_l)
+    b = shard_bounds(n_total, world)
+    assert res_l[: b[1]].max() < res_l.max()  # the case is what it claims to be: rank 0's own maximum would give another spare label
+    expect = po.fuse(res_l, one(lab_r))
+    for sharded in (0, 1):
+        for r in range(world):
+            assert np.array_equal(np.load(tmp_path / f"fused{sharded}_{r}.npy"), expect), (sharded, r)
+            assert np.array_equal(np.load(tmp_path / f"fusedown{sharded}_{r}.npy"), expect[b[r] : b[r + 1]]), (sharded, r)
+
+
+def _emu_engines(n):
+    from lungmask_amd import _native as nat
+    from lungmask_amd.build import build_emu
+
+    lib = nat.Library(build_emu(), allow_emulation=True)
+    return [nat.Engine(0, lib) for _ in range(n)]
+
+
+@pytest.mark.slow
+def test_lminferer_shards_over_engines_in_one_process():
+    """The drop-in class itself on several "GPUs" (VERDICT r04 #2b): `LMInferer(engines=[...])` -- one engine per device,
+    one host thread per engine, exchanges as peer copies (`InProcessGroup`) -- here three emulated engines with the network at the
+    emulator's 32 x 32 resolution.  `apply` returns the reference's result (pre-processing, forward + argmax, utils.postprocessing,
+    reshape_mask; in the fused mode mask.py:223-232): slab-sharded and gathered post-processing, an int32 volume into a
+    caller-owned array, an image that is not LPS, and the fused mode."""
+    from lungmask_amd import volume_io
+    from lungmask_amd.mask import LMInferer
+    from oracle import prepost_oracle as po
+    from oracle import unet_oracle as uo
+
+    engs = _emu_engines(3)
+    try:
+        sd_l, sd_r = uo.synthetic_state_dict(3), uo.synthetic_state_dict(3, seed=77)
+        vol = po.phantom(3, 96, 80, seed=4)
+        xs, boxes = po.preprocess(vol, [32, 32])
+        x = po.normalise(xs)[:, None]
+
+        def one(slot):
+            lab = engs[0].forward(slot, x, want_logp=False)[0]
+            post = po.postprocessing(lab.copy())
+            return np.asarray([po.reshape_mask(post[i], boxes[i], vol.shape[1:]) for i in range(len(post))], dtype=np.uint8)
+
+        # ---- one model, slab-sharded post-processing (the default from three ranks on)
+        inf = LMInferer(state_dict=sd_l, engines=engs, batch_size=2, resolution=(32, 32))
+        assert inf._shard.world == 3 and inf._shard.pipes[0].sharded_post
+        expect = one(0)
+        out = inf.apply(vol)
+        assert out.dtype == np.uint8 and np.array_equal(out, expect), int((out != expect).sum())
+        inf.close()
+        # ---- gathered post-processing; an int32 image that is not LPS (re-oriented on the way in and back on the way out,
+        # mask.py:156-164, 204-208) into a caller-owned array
+        inf = LMInferer(state_dict=sd_l, engines=engs, batch_size=2, resolution=(32, 32), sharded_post=False)
+        direction = (1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, -1.0)  # slices stacked downwards: LPI
+        axes, flips = volume_io.lps_transform(direction)
+        assert (axes, flips) != ((0, 1, 2), (False, False, False))
+        inv = volume_io.inverse_transform(axes, flips)
+        img = volume_io.Volume(np.ascontiguousarray(volume_io.apply_transform(vol.astype(np.int32), *inv)), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0), direction)
+        mine = np.empty(img.array.shape, np.uint8)
+        assert inf.apply(img, out=mine) is mine
+        assert np.array_equal(volume_io.apply_transform(mine, axes, flips), expect)
+        inf.close()
+        # ---- fused mode (a second 3-class model stands in for the fill model)
+        inf = LMInferer(modelname="LTRCLobes", fillmodel="R231", state_dict=sd_l, fill_state_dict=sd_r, engines=engs, batch_size=2, resolution=(32, 32))
+        expect_f = po.fuse(expect, one(1))
+        out_f = inf.apply(vol)
+        assert np.array_equal(out_f, expect_f) and not np.shares_memory(out_f, out)
+        inf.close()
+    finally:
+        for e in engs:
+            e.close()
+
+
+def test_in_process_group_reports_a_failing_rank():
+    """A rank that raises breaks the rendezvous: the other ranks raise too instead of waiting, `apply` re-raises the original
+    error, and the same object works again afterwards."""
+    from lungmask_amd.pipeline import InProcessGroup
+    import threading
+
+    g = InProcessGroup(2)
+    errs = []
+
+    def rank(r):
+        class E:
+            def sync(self):
+                if r == 1:
+                    raise ValueError("rank 1 failed")
+        try:
+            g.member(r, E()).all_gather_into_tensor(torch.zeros(4, dtype=torch.int32), torch.ones(2, dtype=torch.int32))
+        except BaseException as ex:  # noqa: BLE001
+            g.abort()
+            errs.append(type(ex))
+
+    ts = [threading.Thread(target=rank, args=(r,)) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(30)
+    assert sorted(e.__name__ for e in errs) == ["BrokenBarrierError", "ValueError"]
+    g.reset()
+    outs = [torch.zeros(4, dtype=torch.int32) for _ in range(2)]
+
+    class Ok:
+        def sync(self):
+            pass
+
+    ts = [threading.Thread(target=lambda r=r: g.member(r, Ok()).all_gather_into_tensor(outs[r], torch.full((2,), r + 1, dtype=torch.int32))) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(30)
+    assert outs[0].tolist() == [1, 1, 2, 2] and outs[1].tolist() == [1, 1, 2, 2]

@@ -256,7 +256,7 @@ def test_dicom_writer_roundtrip_and_tag_carry_over(tmp_path):
 def test_dicom_writer_left_handed_volume_keeps_every_voxel_in_place(tmp_path):
     """a multi-frame file advances its frames along +cross(row, column).  A left-handed volume (third direction column
     = -cross: e.g. a NIfTI / MetaImage input written to .dcm) goes out with its frames reversed from the position of its last
-    slice, so every voxel reads back at its physical position; an oblique slice axis is refused."""
+    slice, so every voxel reads back at its physical position; an oblique slice axis is written along the in-plane normal with a warning."""
     rng = np.random.default_rng(9)
     lab = rng.integers(0, 4, (5, 6, 7)).astype(np.uint8)
     d = np.array([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, -1.0]])  # columns: row dir, column dir, slice dir = -cross(row, column)
@@ -271,9 +271,14 @@ def test_dicom_writer_left_handed_volume_keeps_every_voxel_in_place(tmp_path):
 
     for z, y, x in ((0, 0, 0), (4, 5, 6), (2, 1, 3)):
         assert np.allclose(pos(vol, z, y, x), pos(got, lab.shape[0] - 1 - z, y, x))
-    bad = vio.Volume(lab, (1, 1, 1), (0, 0, 0), np.array([[1.0, 0, 0.5], [0, 1.0, 0], [0, 0, 0.8660254]]))
-    with pytest.raises(vio.DicomError):
-        vio.save_image(str(tmp_path / "oblique.dcm"), bad, None)
+    # a gantry-tilted series (slice axis 30 degrees off the in-plane normal): the reference's SimpleITK writer accepts it, and the
+    # writer runs after the whole inference -- a warning and the projected geometry, not an error that loses the result
+    tilted = vio.Volume(lab, (1, 1, 2.0), (0, 0, 0), np.array([[1.0, 0, 0.5], [0, 1.0, 0], [0, 0, 0.8660254]]))
+    with pytest.warns(RuntimeWarning, match="not perpendicular"):
+        vio.save_image(str(tmp_path / "oblique.dcm"), tilted, None)
+    got = vio.load_input_image(str(tmp_path / "oblique.dcm"))
+    assert np.array_equal(got.array, lab) and np.allclose(got.spacing, (1, 1, 2.0 * 0.8660254), atol=1e-5)
+    assert np.allclose(np.asarray(got.direction).reshape(3, 3), np.eye(3), atol=1e-6)
 
 
 _CONDA_PY = "/opt/conda/bin/python3.9"  # the interpreter oracle/make_golden.py runs the reference's utils.py under (scikit-image 0.18.3, imageio 2.9)
