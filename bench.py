@@ -71,6 +71,24 @@ def pmc_traffic(kernel_substr):
     return (tot / n if n else None), f"profiles/{pin['file']} (measured on commit {pin.get('commit', '?')}, kernel sources unchanged since)"
 
 
+def cpu_baseline_config1(sd):
+    """BASELINE.json configs[0] itself: the 512 x 512 x 32 synthetic volume, batch 1, through the CPU restatement of the reference
+    (oracle/, kind = 'port'; the reference cannot be imported on the GPU box) -- the whole 32-slice volume, not a sample."""
+    import torch
+
+    from oracle import prepost_oracle as po
+    from oracle import unet_oracle as uo
+
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    vol = po.phantom(32, 512, 512)
+    t = time.perf_counter()
+    po.inference(vol, lambda xb: uo.predict_labels(sd, torch.from_numpy(np.ascontiguousarray(xb))), batch_size=1)
+    dt = time.perf_counter() - t
+    return {"value": round(32 / dt, 3), "unit": "slices/s", "cores": cores, "kind": "port",
+            "sample": f"BASELINE.json configs[0]: the whole 512x512x32 phantom, batch 1, torch-CPU fp32 forward on {cores} threads + scipy pre/post, {dt:.1f} s"}
+
+
 def cpu_baseline(n_sample, sd):
     """The reference algorithm restated on the CPU (oracle/, kind='port'), timed on this host's cores on a
     bounded sample: n_sample central slices of the same phantom, batch 1 (what the reference's --cpu forces)."""
@@ -141,6 +159,97 @@ def cpu_baseline(n_sample, sd):
     except Exception as e:  # noqa: BLE001 -- a baseline must not take the benchmark down
         out["same_gpu_reference_path"] = {"error": repr(e)[:300]}
     return out
+
+
+class ChipSampler:
+    """Shader clock and socket power of one GPU, sampled by a thread WHILE the timed repetitions run, so that a reader of the line
+    can tell a slow box from a slow tree (boxes of this pool differ by +-3 % in the clock they sustain under this load).  Source:
+    the amdgpu hwmon files (one small read per value), else `rocm-smi --json` (a process per sample: coarse).  Failures are
+    recorded in the line, never raised; nothing here touches the GPU's queues."""
+
+    def __init__(self, index, period=0.05):
+        import glob
+        import threading
+
+        self.period, self.samples, self.err, self.source = period, [], None, None
+        self._stop = threading.Event()
+        self._th = None
+        self.files = None
+        try:
+            cards = []
+            for c in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
+                if os.path.basename(c).count("-"):
+                    continue
+                try:
+                    if open(os.path.join(c, "device/vendor")).read().strip() != "0x1002":
+                        continue
+                except OSError:
+                    continue
+                cards.append((os.path.realpath(os.path.join(c, "device")), c))
+            cards.sort()
+            if index < len(cards):
+                hw = sorted(glob.glob(os.path.join(cards[index][1], "device/hwmon/hwmon*")))
+                if hw:
+                    pw = next((os.path.join(hw[0], f) for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(hw[0], f))), None)
+                    fq = os.path.join(hw[0], "freq1_input") if os.path.exists(os.path.join(hw[0], "freq1_input")) else None
+                    if pw or fq:
+                        self.files = (pw, fq)
+                        self.source = f"sysfs hwmon ({cards[index][0].rsplit('/', 1)[-1]})"
+        except Exception as e:  # noqa: BLE001
+            self.err = repr(e)[:200]
+        self.index = index
+
+    def _read(self):
+        if self.files is not None:
+            pw, fq = self.files
+            p = float(open(pw).read()) * 1e-6 if pw else None  # microwatts
+            f = float(open(fq).read()) * 1e-6 if fq else None  # Hz -> MHz
+            return f, p
+        import subprocess
+
+        out = subprocess.run(["rocm-smi", "-d", str(self.index), "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=20).stdout
+        d = json.loads(out)
+        c = d[sorted(d)[0]]
+        f = p = None
+        for k, v in c.items():
+            kl = k.lower()
+            if "sclk clock speed" in kl:
+                f = float(str(v).strip("()").lower().replace("mhz", ""))
+            elif "power" in kl and "(w)" in kl:
+                p = float(v)
+        self.source = "rocm-smi --showclocks --showpower --json (one process per sample)"
+        return f, p
+
+    def start(self):
+        import threading
+
+        def loop():
+            while not self._stop.is_set():
+                try:
+                    self.samples.append((time.perf_counter(),) + tuple(self._read()))
+                except Exception as e:  # noqa: BLE001
+                    self.err = repr(e)[:200]
+                    return
+                self._stop.wait(self.period)
+
+        self._th = threading.Thread(target=loop, daemon=True)
+        self._th.start()
+
+    def stop(self):
+        self._stop.set()
+        if self._th is not None:
+            self._th.join(30)
+
+    def summary(self, t_begin, t_end):
+        def stat(vals):
+            v = sorted(x for x in vals if x is not None)
+            return None if not v else {"min": round(v[0], 1), "median": round(v[len(v) // 2], 1), "max": round(v[-1], 1)}
+
+        inside = [s for s in self.samples if t_begin <= s[0] <= t_end]
+        return {"sclk_mhz": stat(s[1] for s in inside), "socket_power_w": stat(s[2] for s in inside), "samples": len(inside), "period_s": self.period,
+                "source": self.source, "error": self.err,
+                "note": "sampled by a host thread while the timed repetitions ran (the contract's timed region and the extra ones); the chip "
+                        "clocks to its power budget, and boxes of this pool differ by a few per cent in the clock they sustain under this load"}
 
 
 def _free_port():
@@ -239,14 +348,14 @@ def main():
                     help="N>1 collectives: torch.distributed (backend nccl = RCCL) or the engine's own RCCL communicator behind the C ABI (lm_dist_*)")
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2], help="forward lanes (2: consecutive batches overlap on two streams)")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4], help="BASELINE.json configuration: 2 R231 (the headline), 3 LTRCLobes, 4 LTRCLobes_R231 fused")
+    ap.add_argument("--repeat", type=int, default=2, help="extra repetitions of the timed region, reported as min / median / max beside `value`")
     ap.add_argument("--host-steps", type=int, default=-1,
                     help="steps of the two numpy -> numpy measurements beside `value` (lm_apply_host and LMInferer.apply); default: --steps, 0 to skip")
     args = ap.parse_args()
     cfg_name, n_classes, fill_classes = CONFIGS[args.config]
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
-    if args.gpus > 1 and args.config != 2:
-        raise SystemExit("configs 3 and 4 are single-GPU configurations (BASELINE.json)")
+    # (BASELINE.json quotes configs 3 and 4 on one GPU; the sharded pipeline runs them on N as well -- SURVEY 8e rows 1-4)
     if args.host_steps < 0:
         args.host_steps = args.steps
     # TEST HOOK (tests/test_bench_spawn.py, CPU suite): LM_BENCH_EMU=1 runs this same script on the g++ emulation of the kernels
@@ -351,7 +460,7 @@ def main():
 
         vt = torch.from_numpy(vol).to(dev)
         pipe = ShardedPipeline(eng, slot=0, batch_size=args.batch, resolution=res, dist=dist if dist is not None else group.nd, device=dev,
-                               sharded_post=None if args.post == "auto" else args.post == "slab")
+                               sharded_post=None if args.post == "auto" else args.post == "slab", fill_slot=fill_slot)
         args.post = "slab" if pipe.sharded_post else "gathered"  # (what the line reports)
 
         def step():
@@ -361,20 +470,39 @@ def main():
         step()
     eng.profile(3)  # HIP events around the dominant kernel's launches only (events around every launch cost ~1 %)
     eng.profile_reset()
+    def over_ranks(v):
+        if dist is not None:
+            tt = torch.tensor([v], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        return group.max(v) if group is not None else v
+
+    sampler = ChipSampler(local_rank) if (rank == 0 and not emu) else None
+    if sampler is not None:
+        sampler.start()
+    # ---- the contract's timed region: exactly --steps steps between barrier + synchronise on both sides, max over ranks
     sync_all()
-    t0 = time.perf_counter()
+    t_first = t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync_all()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    elif group is not None:
-        dt = group.max(dt)
+    dt = over_ranks(time.perf_counter() - t0)
     stats = eng.profile_read()
     eng.profile(False)
+    # ---- the same region again, --repeat more times (reported under `repetitions`; `value` / `ms_per_step` stay the first region's)
+    rep_ms = [dt / args.steps * 1e3]
+    for _ in range(max(args.repeat, 0)):
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync_all()
+        rep_ms.append(over_ranks(time.perf_counter() - t0) / args.steps * 1e3)
+    t_last = time.perf_counter()
+    chip = None
+    if sampler is not None:
+        sampler.stop()
+        chip = sampler.summary(t_first, t_last)
     post_info = eng.postprocess_info()
     if not use_dist and rank == 0:  # what the label volume of this workload looks like (post-processing cost is data dependent)
         fin = od.download()
@@ -510,6 +638,10 @@ def main():
                 "weights": weights,
                 "parallelism": "single GPU" if not use_dist else (f"slice-sharded x{world}: slab-local post-processing + 6 small RCCL table all-gathers, 1 all-gather of the output" if args.post == "slab" else f"slice-sharded x{world}: RCCL all-gather of the labels, redundant whole-volume post-processing, all-gather of the output"),
             },
+            "repetitions": {"ms_per_step": [round(v, 3) for v in rep_ms], "min": round(min(rep_ms), 3), "median": round(sorted(rep_ms)[len(rep_ms) // 2], 3),
+                            "max": round(max(rep_ms), 3), "steps_each": args.steps,
+                            "note": "the timed region repeated back to back; the first entry is the contract's region (`value`, `ms_per_step`)"},
+            "chip_during_timed_region": chip,
             "end_to_end_tflops": round(value * (FLOP_PER_SLICE[n_classes] + (FLOP_PER_SLICE[fill_classes] if fill_classes else 0.0)) / 1e12, 2),
             "value_definition": "`value` = device-resident (contract: inputs in HBM when the timed region starts); value_host_to_host / "
                                 "value_lminferer_apply = the same step numpy -> numpy over the same number of steps (SURVEY 8d's definition)",
@@ -525,6 +657,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and not emu:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, sd)
+            out["cpu_baseline_config1"] = cpu_baseline_config1(sd)
     # The JSON line must be the LAST line of the job's stdout: RCCL prints a version banner through C stdio, which is
     # block-buffered on a pipe and would otherwise be flushed at exit, after Python's own output -- on every rank.
     import ctypes

@@ -295,8 +295,9 @@ class LMInferer:
         if sh is not None:
             sh.close()
             self._shard = None
-        if getattr(self, "_own_engine", False) and getattr(self, "engine", None) is not None:
-            self.engine.close()
+        if getattr(self, "_own_engine", False):
+            for eng in getattr(self, "_engines", []):
+                eng.close()
         self._own_engine = False
 
     def __del__(self):

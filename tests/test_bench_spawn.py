@@ -39,7 +39,7 @@ def test_world_size_must_match_gpus():
     assert r.returncode != 0 and "--gpus 1 but WORLD_SIZE=2" in r.stderr
 
 
-def _check_line(r, n_local):
+def _check_line(r, n_local, repeat=0):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout  # rank 0 only
@@ -49,14 +49,18 @@ def _check_line(r, n_local):
     assert "EMULATION TEST HOOK" in out["data"]
     assert f"96x80x{n_local} int16 HU phantom per GPU ({2 * n_local} slices total)" in out["config"]["workload"]
     assert "cpu_baseline" not in out
+    # the timed region repeated: the first entry is the contract's region
+    rep = out["repetitions"]
+    assert len(rep["ms_per_step"]) == 1 + repeat and rep["ms_per_step"][0] == out["ms_per_step"] and rep["min"] <= rep["median"] <= rep["max"]
+    assert out["chip_during_timed_region"] is None  # (no chip to sample under emulation)
 
 
 def test_self_spawned_two_ranks_over_gloo_and_the_emulator():
     from lungmask_amd.build import build_emu
 
     build_emu()  # once, before two ranks race to build it
-    r = _run(["--gpus", "2", "--slices", "2", "--steps", "1", "--warmup", "0", "--batch", "2", "--no-cpu-baseline"], {"LM_BENCH_EMU": "1"})
-    _check_line(r, 2)
+    r = _run(["--gpus", "2", "--slices", "2", "--steps", "1", "--warmup", "0", "--batch", "2", "--no-cpu-baseline", "--repeat", "1"], {"LM_BENCH_EMU": "1"})
+    _check_line(r, 2, repeat=1)
 
 
 def test_two_ranks_under_torch_distributed_run():
@@ -75,5 +79,5 @@ def test_two_ranks_under_torch_distributed_run():
     env.update(LM_BENCH_EMU="1", OMP_NUM_THREADS="4")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), BENCH, "--gpus", "2", "--slices", "1", "--steps", "1", "--warmup", "0", "--batch", "2",
-                        "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+                        "--no-cpu-baseline", "--repeat", "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     _check_line(r, 1)
