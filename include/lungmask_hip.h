@@ -190,6 +190,15 @@ int lm_apply_dev(lm_engine* e, int slot, int fill_slot, const void* vol_dev, int
 int lm_apply_host(lm_engine* e, int slot, int fill_slot, const void* vol_host, int dtype, int n, int h, int w,
                   int batch_size, int volume_postprocessing, uint8_t* out_host);
 
+/* lm_apply_host with flags.  LM_APPLY_OUT_SCRATCH: the previous contents of out_host are of no value to the caller (a result
+ * array the binding allocated itself, mask.py:210) -- the engine may write it before the call is known to succeed: a helper thread
+ * fills it with zeros while the network runs, and only the slab of slices x image rows that carries a label is copied back (one
+ * strided device-to-host copy).  Without the flag (== lm_apply_host) out_host is only written by the final copy of a successful
+ * call.  The labels are the same either way. */
+#define LM_APPLY_OUT_SCRATCH 1u
+int lm_apply_host_ex(lm_engine* e, int slot, int fill_slot, const void* vol_host, int dtype, int n, int h, int w,
+                     int batch_size, int volume_postprocessing, uint8_t* out_host, unsigned flags);
+
 /* The batch loop of mask.py:173-187 in one call: n slices in batches of batch_size.  With two forward
  * lanes (default; lm_set_streams(e, 1) disables) consecutive batches alternate between two HIP streams and
  * workspaces so that one batch's kernel tails are filled by the next batch's work; results are identical. */

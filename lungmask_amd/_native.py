@@ -102,6 +102,8 @@ class Library:
         L.lm_fuse_spare_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         L.lm_apply_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
         L.lm_apply_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
+        if hasattr(L, "lm_apply_host_ex"):  # (absent from older builds that tools/ab_forward.py may load for comparison)
+            L.lm_apply_host_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_uint]
         L.lm_profile_enable.argtypes = [C.c_void_p, C.c_int]
         L.lm_profile_reset.argtypes = [C.c_void_p]
         L.lm_profile_read.argtypes = [C.c_void_p, C.POINTER(KernelStat), C.c_int]
@@ -411,21 +413,24 @@ class Engine:
         )
 
     def apply(self, slot: int, vol: np.ndarray, fill_slot: int = -1, batch_size: int = 20, volume_postprocessing: bool = True,
-              out: Optional[np.ndarray] = None) -> np.ndarray:
+              out: Optional[np.ndarray] = None, out_scratch: bool = False) -> np.ndarray:
         """numpy -> numpy (lm_apply_host).  `out`: an optional caller-owned uint8 C-contiguous array of the volume's shape to
-        receive the labels (a reused buffer spares the page faults and the unmapping of a fresh 79 MB array per volume)."""
+        receive the labels (a reused buffer spares the page faults and the unmapping of a fresh 79 MB array per volume).
+        `out_scratch`: the contents of `out` are of no value (LM_APPLY_OUT_SCRATCH): it is zero-filled while the network runs and
+        only the slab that carries labels is copied back; always so for an array allocated here."""
         vol = np.ascontiguousarray(vol)
         if vol.dtype not in LM_DTYPES:
             raise LMError(f"unsupported volume dtype {vol.dtype}")
         n, h, w = vol.shape
         if out is None:
-            out = np.empty((n, h, w), dtype=np.uint8)
+            out, out_scratch = np.empty((n, h, w), dtype=np.uint8), True
         elif out.dtype != np.uint8 or out.shape != (n, h, w) or not out.flags.c_contiguous:
             raise LMError("apply(out=...): need a C-contiguous uint8 array of the volume's shape")
-        self.L.check(
-            self.L.lib.lm_apply_host(self.h, slot, fill_slot, vol.ctypes.data, LM_DTYPES[vol.dtype], n, h, w, int(batch_size), int(bool(volume_postprocessing)), out.ctypes.data),
-            "lm_apply_host",
-        )
+        args = (self.h, slot, fill_slot, vol.ctypes.data, LM_DTYPES[vol.dtype], n, h, w, int(batch_size), int(bool(volume_postprocessing)), out.ctypes.data)
+        if out_scratch and hasattr(self.L.lib, "lm_apply_host_ex"):
+            self.L.check(self.L.lib.lm_apply_host_ex(*args, 1), "lm_apply_host_ex")
+        else:
+            self.L.check(self.L.lib.lm_apply_host(*args), "lm_apply_host")
         return out
 
     # -- profiling

@@ -77,6 +77,10 @@ def build_emu(force: bool = False, verbose: bool = False) -> str:
             arch = ["-mfma", "-mavx2"]
     except OSError:
         pass
+    # LM_EMU_EXTRA_FLAGS: extra -D switches for a variant of the emulator (e.g. -DLM_H3_FOLD_SCALE=0 to run the suite on the other
+    # form of the kernels); part of the stamp, so switching rebuilds
+    extra_flags = os.environ.get("LM_EMU_EXTRA_FLAGS", "").split()
+    arch = arch + extra_flags
     stamp = os.path.join(outdir, "flags.txt")
     want = " ".join(arch)
     have = open(stamp).read() if os.path.exists(stamp) else None

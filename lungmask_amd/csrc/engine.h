@@ -56,6 +56,9 @@ struct ConvLayer {
     // (1 top, 2 bottom, 4 left, 8 right) of S[tap][co] (zero padding pads the TRUE activation, not r).
     float *bias_h3 = nullptr, *corr_h3 = nullptr;
     std::vector<float> h_bn_t;  // host copy of this layer's own shift (empty: no BatchNorm)
+    // LM_H3_FOLD_SCALE: what a consumer multiplies this layer's stored channel by (s / 2^E; empty: 1) and the layer's 2^E
+    std::vector<float> h_fold_s;
+    float fold_pow2 = 1.f;
 };
 
 struct Model {
@@ -68,6 +71,8 @@ struct Model {
     float *head_w = nullptr, *head_b = nullptr;
     float* head_b_h3 = nullptr;  // head bias + head_w . (shift of the last conv): the head reads an r-form tensor
     float* zeros_h3 = nullptr;   // 1024 zeros: the "shift" a deferred-shift producer applies
+    float* ones_h3 = nullptr;    // 1024 ones: the "scale" of a producer whose scale its consumers carry (LM_H3_FOLD_SCALE)
+    float* head_w_h3 = nullptr;  // head weights times the last conv's folded scale (== head_w without the fold)
     float* fc_pack = nullptr;    // first conv for the fused loader (ConvParamsH3::fc_c): w[9][64] | bias[64] | bn scale[64]
     std::vector<void*> allocs;
     // The split-f16 path stores activations as f16 pairs: a model whose activations left the f16 range (detected by the

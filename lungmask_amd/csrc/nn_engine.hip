@@ -212,11 +212,34 @@ float f16_to_f32(uint16_t h) {
 // resunet.py:97-100 -- it cannot be folded into the conv).
 // t_in: the per-channel shift T carried by this layer's INPUT tensor in the split-f16 path's deferred-shift form (nullptr:
 // none) -- see ConvLayer::bias_h3.
+// s_in (LM_H3_FOLD_SCALE): the per-channel factor the INPUT tensor's producer left to its consumers (ConvLayer::h_fold_s; nullptr: 1).
 int load_conv(Model& md, const TensorMap& tm, const std::string& conv, const std::string& bnp, int cin, int cout, int taps, ConvLayer* L,
-              const std::vector<float>* t_in = nullptr) {
+              const std::vector<float>* t_in = nullptr, const std::vector<float>* s_in = nullptr) {
     const lm_tensor* w = tm.get(conv + ".weight", (int64_t)cout * cin * taps);
     const lm_tensor* b = tm.get(conv + ".bias", cout);
     if (!w || !b) return LM_ERR_INVALID;
+    // This layer's own BatchNorm scale, as its consumers will carry it (LM_H3_FOLD_SCALE): s[co] / 2^E with 2^E the power of two
+    // below the median |s| -- the stored tensor relu(.) * 2^E then has the magnitude BatchNorm would have given it.
+    float own_pow2 = 1.f;
+    if (LM_H3_FOLD_SCALE && !bnp.empty()) {
+        const lm_tensor* g = tm.get(bnp + ".weight", cout);
+        const lm_tensor* var = tm.get(bnp + ".running_var", cout);
+        if (!g || !var) return LM_ERR_INVALID;
+        std::vector<double> sd(cout), mag;
+        for (int o = 0; o < cout; ++o) {
+            sd[o] = (double)g->data[o] / std::sqrt((double)var->data[o] + 1e-5);
+            if (std::isfinite(sd[o]) && sd[o] != 0.0) mag.push_back(std::fabs(sd[o]));
+        }
+        if (!mag.empty()) {
+            std::nth_element(mag.begin(), mag.begin() + mag.size() / 2, mag.end());
+            int e = 0;
+            (void)std::frexp(mag[mag.size() / 2], &e);  // median = m * 2^e, m in [0.5, 1)
+            own_pow2 = std::ldexp(1.f, std::min(std::max(e - 1, -60), 60));
+        }
+        L->h_fold_s.resize(cout);
+        for (int o = 0; o < cout; ++o) L->h_fold_s[o] = (float)(sd[o] / (double)own_pow2);
+        L->fold_pow2 = own_pow2;
+    }
     {
         // S[tap][co] = sum_ci w[co][ci][tap] * T[ci] in double; bias_h3 = bias + all taps; corr_h3[mask] = the taps that the
         // border mask (1 top, 2 bottom, 4 left, 8 right) puts outside the image
@@ -232,7 +255,7 @@ int load_conv(Model& md, const TensorMap& tm, const std::string& conv, const std
         for (int o = 0; o < cout; ++o) {
             double full = 0;
             for (int t = 0; t < taps; ++t) full += S[(size_t)t * cout + o];
-            be[o] = (float)((double)b->data[o] + full);
+            be[o] = (float)(((double)b->data[o] + full) * (double)own_pow2);  // (own_pow2 == 1 without the fold)
             if (taps == 9)
                 for (int mask = 1; mask < 16; ++mask) {
                     double c = 0;
@@ -240,7 +263,7 @@ int load_conv(Model& md, const TensorMap& tm, const std::string& conv, const std
                         const int dy = t / 3, dx = t % 3;
                         if (((mask & 1) && dy == 0) || ((mask & 2) && dy == 2) || ((mask & 4) && dx == 0) || ((mask & 8) && dx == 2)) c += S[(size_t)t * cout + o];
                     }
-                    corr[(size_t)mask * cout + o] = (float)c;
+                    corr[(size_t)mask * cout + o] = (float)(c * (double)own_pow2);
                 }
         }
         LM_TRY(upload(md, be, &L->bias_h3));
@@ -256,8 +279,15 @@ int load_conv(Model& md, const TensorMap& tm, const std::string& conv, const std
         // k: the layer's largest |w'| lands in [1024, 2048) (a factor 32 below the f16 maximum), so the remainder of every
         // weight down to 2^-14 of the largest one is a NORMAL f16 number (full 11-bit precision of lo -> 2^-22 relative on
         // w, also for heavy-tailed trained weights); 2^-k goes back in through the epilogue.
+        const bool fold_in = LM_H3_FOLD_SCALE && s_in != nullptr && (int)s_in->size() == cin;
+        auto wf = [&](int o, int i, int t) -> float {  // the weight the matrix cores see: w * s_in[ci] (one rounding, from double)
+            const float v = w->data[((size_t)o * cin + i) * taps + t];
+            return fold_in ? (float)((double)v * (double)(*s_in)[i]) : v;
+        };
         float wmax = 0.f;
-        for (size_t j = 0; j < (size_t)taps * cout * cin; ++j) wmax = std::max(wmax, std::fabs(w->data[j]));
+        for (int o = 0; o < cout; ++o)
+            for (int i = 0; i < cin; ++i)
+                for (int t = 0; t < taps; ++t) wmax = std::max(wmax, std::fabs(wf(o, i, t)));
         int k = 0;
         if (wmax > 0.f && std::isfinite(wmax)) {
             int e = 0;
@@ -265,13 +295,13 @@ int load_conv(Model& md, const TensorMap& tm, const std::string& conv, const std
             k = 11 - e;                  // wmax * 2^k in [1024, 2048)
         }
         const float up = std::ldexp(1.f, k);
-        L->h3_acc_scale = std::ldexp(1.f, -k);
+        L->h3_acc_scale = std::ldexp(1.f, -k) * own_pow2;
         std::vector<float> ph((size_t)taps * cout * cin);  // 4 bytes per element, viewed as halves below
         uint16_t* hp = reinterpret_cast<uint16_t*>(ph.data());
         for (int t = 0; t < taps; ++t)
             for (int o = 0; o < cout; ++o)
                 for (int i = 0; i < cin; ++i) {
-                    const float v = w->data[((size_t)o * cin + i) * taps + t] * up;
+                    const float v = wf(o, i, t) * up;
                     const uint16_t hi = f32_to_f16(v);
                     const uint16_t lo = (uint16_t)lm_round_lo_pair(f32_to_f16(v - f16_to_f32(hi)));  // same rule as the activations
                     const size_t g = (((size_t)t * cout + o) * cin + (size_t)(i & ~7)) * 2;  // half index of the group start
@@ -331,24 +361,31 @@ int model_load(lm_engine* e, int slot, const lm_tensor* tensors, int n) {
     // the layer that produced it -- pooling and the bilinear upsample pass a per-channel constant through unchanged; the 1x1
     // convs have no BatchNorm and emit true values)
     int prev = 1;
+    const auto fs = [](const ConvLayer& L) -> const std::vector<float>* { return (LM_H3_FOLD_SCALE && !L.h_fold_s.empty()) ? &L.h_fold_s : nullptr; };
     for (int i = 0; i < 5; ++i) {
         const int co = 64 << i;
         const std::string p = "down_path." + std::to_string(i) + ".block.";
         if (i == 0)
             LM_TRY(load_conv(md, tm, p + "0", p + "2", 1, co, 9, &md.first));
         else
-            LM_TRY(load_conv(md, tm, p + "0", p + "2", prev, co, 9, &md.down[i][0], &md.down[i - 1][1].h_bn_t));  // pooled skip tensor
-        LM_TRY(load_conv(md, tm, p + "3", p + "5", co, co, 9, &md.down[i][1], i == 0 ? &md.first.h_bn_t : &md.down[i][0].h_bn_t));
+            LM_TRY(load_conv(md, tm, p + "0", p + "2", prev, co, 9, &md.down[i][0], &md.down[i - 1][1].h_bn_t, fs(md.down[i - 1][1])));  // pooled skip tensor
+        const ConvLayer& src = i == 0 ? md.first : md.down[i][0];
+        LM_TRY(load_conv(md, tm, p + "3", p + "5", co, co, 9, &md.down[i][1], &src.h_bn_t, fs(src)));
         prev = co;
     }
     for (int i = 0; i < 4; ++i) {
         const int co = 512 >> i;
         const std::string p = "up_path." + std::to_string(i);
-        LM_TRY(load_conv(md, tm, p + ".up.1", "", prev, co, 1, &md.up1x1[i], i == 0 ? &md.down[4][1].h_bn_t : &md.upc[i - 1][1].h_bn_t));
-        std::vector<float> t_cat(2 * (size_t)co, 0.f);  // torch.cat([up, bridge], 1) (resunet.py:147): the up half is exact, the skip half shifted
-        std::copy(md.down[3 - i][1].h_bn_t.begin(), md.down[3 - i][1].h_bn_t.end(), t_cat.begin() + co);
-        LM_TRY(load_conv(md, tm, p + ".conv_block.block.0", p + ".conv_block.block.2", prev, co, 9, &md.upc[i][0], &t_cat));
-        LM_TRY(load_conv(md, tm, p + ".conv_block.block.3", p + ".conv_block.block.5", co, co, 9, &md.upc[i][1], &md.upc[i][0].h_bn_t));
+        const ConvLayer& below = i == 0 ? md.down[4][1] : md.upc[i - 1][1];
+        LM_TRY(load_conv(md, tm, p + ".up.1", "", prev, co, 1, &md.up1x1[i], &below.h_bn_t, fs(below)));
+        // torch.cat([up, bridge], 1) (resunet.py:147): the up half is exact (no BatchNorm behind the 1x1 conv), the skip half carries
+        // the shift -- and with LM_H3_FOLD_SCALE the scale -- of the encoder conv that wrote it
+        std::vector<float> t_cat(2 * (size_t)co, 0.f), s_cat(2 * (size_t)co, 1.f);
+        const ConvLayer& skip = md.down[3 - i][1];
+        std::copy(skip.h_bn_t.begin(), skip.h_bn_t.end(), t_cat.begin() + co);
+        if (fs(skip)) std::copy(skip.h_fold_s.begin(), skip.h_fold_s.end(), s_cat.begin() + co);
+        LM_TRY(load_conv(md, tm, p + ".conv_block.block.0", p + ".conv_block.block.2", prev, co, 9, &md.upc[i][0], &t_cat, LM_H3_FOLD_SCALE ? &s_cat : nullptr));
+        LM_TRY(load_conv(md, tm, p + ".conv_block.block.3", p + ".conv_block.block.5", co, co, 9, &md.upc[i][1], &md.upc[i][0].h_bn_t, fs(md.upc[i][0])));
         prev = co;
     }
     const lm_tensor* hw = tm.get("last.weight", (int64_t)C * 64);
@@ -356,26 +393,33 @@ int model_load(lm_engine* e, int slot, const lm_tensor* tensors, int n) {
     LM_TRY(upload(md, std::vector<float>(hw->data, hw->data + C * 64), &md.head_w));
     LM_TRY(upload(md, std::vector<float>(it->second->data, it->second->data + C), &md.head_b));
     {
-        std::vector<float> hb(C);
+        std::vector<float> hb(C), hwf(hw->data, hw->data + C * 64);
         for (int c = 0; c < C; ++c) {
             double a = it->second->data[c];
             for (int k = 0; k < 64; ++k) a += (double)hw->data[c * 64 + k] * (double)md.upc[3][1].h_bn_t[k];
             hb[c] = (float)a;
+            if (fs(md.upc[3][1]))  // the head reads the last conv's stored (or, fused, its fp32) relu(.) * 2^E: its weights carry s / 2^E
+                for (int k = 0; k < 64; ++k) hwf[c * 64 + k] = (float)((double)hw->data[c * 64 + k] * (double)md.upc[3][1].h_fold_s[k]);
         }
         LM_TRY(upload(md, hb, &md.head_b_h3));
+        LM_TRY(upload(md, hwf, &md.head_w_h3));
         LM_TRY(upload(md, std::vector<float>(1024, 0.f), &md.zeros_h3));
+        LM_TRY(upload(md, std::vector<float>(1024, 1.f), &md.ones_h3));
     }
-    {   // the first conv as the fused loader of its consumer wants it (ConvParamsH3::fc_c): the arrays load_conv uploaded, in one piece
+    {   // the first conv as the split-f16 path wants it (ConvParamsH3::fc_c for the fused loader; first_conv_h3_kernel takes the same three
+        // arrays): w[9][64] | bias[64] | scale[64].  With LM_H3_FOLD_SCALE weights and bias are times the layer's 2^E (exact) and the
+        // scale is 1: relu(x * 2^E) == relu(x) * 2^E, and the consumers carry s / 2^E.
         const lm_tensor* w = tm.get("down_path.0.block.0.weight", 64 * 9);
         const lm_tensor* b = tm.get("down_path.0.block.0.bias", 64);
         const lm_tensor* g = tm.get("down_path.0.block.2.weight", 64);
         const lm_tensor* var = tm.get("down_path.0.block.2.running_var", 64);
         if (!w || !b || !g || !var) return LM_ERR_INVALID;
+        const float e2 = LM_H3_FOLD_SCALE ? md.first.fold_pow2 : 1.f;
         std::vector<float> pk(9 * 64 + 128);
         for (int o = 0; o < 64; ++o) {
-            for (int t = 0; t < 9; ++t) pk[(size_t)t * 64 + o] = w->data[(size_t)o * 9 + t];
-            pk[576 + o] = b->data[o];
-            pk[640 + o] = (float)((double)g->data[o] / std::sqrt((double)var->data[o] + 1e-5));
+            for (int t = 0; t < 9; ++t) pk[(size_t)t * 64 + o] = w->data[(size_t)o * 9 + t] * e2;
+            pk[576 + o] = b->data[o] * e2;
+            pk[640 + o] = LM_H3_FOLD_SCALE ? 1.f : (float)((double)g->data[o] / std::sqrt((double)var->data[o] + 1e-5));
         }
         LM_TRY(upload(md, pk, &md.fc_pack));
     }
@@ -394,6 +438,7 @@ struct Fwd {
     bool h3;  // split-f16 kernels (else the exact-fp32 ones)
     bool defer = false;            // split-f16 only: BatchNorm shifts deferred to the consumers (ConvLayer::bias_h3)
     const float* zeros = nullptr;  // Model::zeros_h3
+    const float* ones = nullptr;   // Model::ones_h3
 
     bool head_fused = false;  // set by conv() when the head ran inside the last conv's epilogue
     NNWorkspace* ws = nullptr;
@@ -443,7 +488,7 @@ struct Fwd {
             q.w = L.w_h3;
             q.acc_scale = L.h3_acc_scale;
             q.bias = defer ? L.bias_h3 : L.bias;
-            q.bn_s = L.bn_s;
+            q.bn_s = (LM_H3_FOLD_SCALE && L.bn_s) ? ones : L.bn_s;  // folded scale: the consumers carry it (nn_kernels.h)
             q.bn_t = (defer && L.bn_t) ? zeros : L.bn_t;  // deferred shift: the consumers add it (ConvLayer::bias_h3)
             q.border_corr = defer ? L.corr_h3 : nullptr;
             q.out = reinterpret_cast<char*>(out);
@@ -525,8 +570,9 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
           e->prof.kind_id("first_conv"), e->prof.kind_id("upsample2x"), e->prof.kind_id("head_argmax"), h3};
     // LM_H3_DEFER_SHIFT=0: A/B hook (the tensors then hold the true activations, as in the exact-fp32 path)
     static const bool defer_ok = [] { const char* v = getenv("LM_H3_DEFER_SHIFT"); return !(v && v[0] == '0'); }();
-    f.defer = h3 && defer_ok;
+    f.defer = h3 && (defer_ok || LM_H3_FOLD_SCALE);  // (the folded scale presupposes the deferred shift)
     f.zeros = md.zeros_h3;
+    f.ones = md.ones_h3;
     f.ws = &ws;
     if (h3 && !e->zero_page) {
         void* zp = nullptr;
@@ -562,6 +608,11 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
     }
     if (!(abl & 1) && !fuse_first) {
         FirstConvParams p{x, md.first.w, md.first.bias, md.first.bn_s, f.defer ? md.zeros_h3 : md.first.bn_t, t1, 64, 0, B, H, W, h3 ? e->range_flag : nullptr};
+        if (h3 && LM_H3_FOLD_SCALE) {  // weights and bias times the layer's 2^E, scale 1 (Model::fc_pack)
+            p.w = md.fc_pack;
+            p.bias = md.fc_pack + 576;
+            p.bn_s = md.fc_pack + 640;
+        }
         e->prof.begin(stream, f.kfirst, 2.0 * px * 64 * 9, 4.0 * px * 65);
         hipError_t err = h3 ? launch_first_conv_h3(p, stream) : launch_first_conv(p, stream);
         e->prof.end(stream);
@@ -598,12 +649,12 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
         }
         LM_TRY(f.conv(md.upc[i][0], ws.cat[lvl].as<float>(), 2 * c, 0, h, w, t1, c, 0));
         // the last conv takes the head (1x1 conv + argmax, + log-softmax when asked for) into its epilogue
-        const HeadParams hp{t3, md.head_w, f.defer ? md.head_b_h3 : md.head_b, labels, logp, B, H, W, md.n_classes};
+        const HeadParams hp{t3, h3 ? md.head_w_h3 : md.head_w, f.defer ? md.head_b_h3 : md.head_b, labels, logp, B, H, W, md.n_classes};
         LM_TRY(f.conv(md.upc[i][1], t1, c, 0, h, w, t3, c, 0, nullptr, 0, 0, i == 3 ? &hp : nullptr));
     }
     // ---- head (resunet.py:69-70, mask.py:184-186)
     if (!f.head_fused) {
-        HeadParams p{t3, md.head_w, f.defer ? md.head_b_h3 : md.head_b, labels, logp, B, H, W, md.n_classes};
+        HeadParams p{t3, h3 ? md.head_w_h3 : md.head_w, f.defer ? md.head_b_h3 : md.head_b, labels, logp, B, H, W, md.n_classes};
         e->prof.begin(stream, f.khead, 2.0 * px * 64 * md.n_classes, 4.0 * px * 64 + px);
         hipError_t err = h3 ? launch_head_h3(p, stream) : launch_head(p, stream);
         e->prof.end(stream);

@@ -363,12 +363,18 @@ __device__ __forceinline__ float4 as_float4(const lm_h16x8& v) {
 // HEAD: the fused-head form of the epilogue (last decoder conv; 1: labels only, 2: labels + log-probabilities) -- separate
 // instantiations, so that the 16 other launches of a forward do not carry its registers.
 // epilogue constants (bias, BN scale, BN shift) of 4 consecutive channels from the item's staged arrays
+#if LM_H3_FOLD_SCALE  // the bias only: scale and shift of the layer travel with its consumers' weights and biases
+#define H3P_EPI_READS(E, CL) LM_LDS_READ128(E[0], ep + (CL) * 4, 0)
+#define H3P_EPI_WAIT(NEXT, E) LM_LDS_WAIT1((NEXT) ? 1 : 0, E[0])
+#else
 #define H3P_EPI_READS(E, CL)                        \
     do {                                            \
         LM_LDS_READ128(E[0], ep + (CL) * 4, 0);     \
         LM_LDS_READ128(E[1], ep + (CL) * 4, TN * 4); \
         LM_LDS_READ128(E[2], ep + (CL) * 4, 2 * TN * 4); \
     } while (0)
+#define H3P_EPI_WAIT(NEXT, E) LM_LDS_WAIT3((NEXT) ? 3 : 0, E[0], E[1], E[2])
+#endif
 #define H3P_EPI_CL(MG) (32 * ((MG) >> 2) + 8 * ((MG) & 3) + 4 * kb)
 
 // ---- PROD = 1: the first layer of the network inside this kernel's loader (ConvParamsH3::fc_x) -------------------------------
@@ -624,6 +630,22 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
 #if defined(LM_FC_ABL) && LM_FC_ABL == 2  // lab ablation: no multiply-adds (timing only)
                     if (k > 0) return;
 #endif
+#ifndef LM_PROD_SCALAR_FMA
+#define LM_PROD_SCALAR_FMA 1
+#endif
+#if LM_PROD_SCALAR_FMA  // four v_fma_f32 instead of two v_pk_fma_f32 (same bits; 0 = the packed form of round 4, the A/B arm of profiles/r05a_*)
+                    {
+                        const float xk = pr_x[k >> 1][k & 1];
+                        float a0 = pr_a[0][0], a1 = pr_a[0][1], a2 = pr_a[1][0], a3 = pr_a[1][1];
+                        lm_fma_f32_single(a0, xk, w[0]);
+                        lm_fma_f32_single(a1, xk, w[1]);
+                        lm_fma_f32_single(a2, xk, w[2]);
+                        lm_fma_f32_single(a3, xk, w[3]);
+                        pr_a[0] = lm_f32x2{a0, a1};
+                        pr_a[1] = lm_f32x2{a2, a3};
+                        return;
+                    }
+#endif
                     const lm_f32x2 w01 = {w[0], w[1]}, w23 = {w[2], w[3]};
                     if (k & 1) {
                         lm_pk_fma_bcast<1>(pr_a[0], pr_x[k >> 1], w01);
@@ -665,15 +687,21 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                     fma2(5, pr_w[1]);
                 } else if (m == 4) {
                     pr_w[0] = ldw(8);
+#if !LM_H3_FOLD_SCALE
                     pr_w[1] = ldw(10);  // BatchNorm scale
+#endif
                     fma2(6, pr_w[2]);
                     fma2(7, pr_w[3]);
                 } else {
                     fma2(8, pr_w[0]);
                     // ReLU, BatchNorm scale; the shift is deferred to this conv's bias and border table (fmaf(., s, 0): what the
                     // stand-alone kernel evaluates with its zero shift array)
+#if LM_H3_FOLD_SCALE  // (weights and bias carry the layer's 2^E, the scale travels with this conv's weights: fmaf(., 1, 0) of the stand-alone kernel)
+                    const float v0 = fmaxf(pr_a[0][0], 0.f), v1 = fmaxf(pr_a[0][1], 0.f), v2 = fmaxf(pr_a[1][0], 0.f), v3 = fmaxf(pr_a[1][1], 0.f);
+#else
                     const float v0 = fmaf(fmaxf(pr_a[0][0], 0.f), pr_w[1][0], 0.f), v1 = fmaf(fmaxf(pr_a[0][1], 0.f), pr_w[1][1], 0.f);
                     const float v2 = fmaf(fmaxf(pr_a[1][0], 0.f), pr_w[1][2], 0.f), v3 = fmaf(fmaxf(pr_a[1][1], 0.f), pr_w[1][3], 0.f);
+#endif
                     // zero padding of THIS conv: halo pixels outside the image are 0 (one unsigned compare per axis)
                     const bool inside = (unsigned)(pr_y0 - 1 + py) < (unsigned)p.H && (unsigned)(pr_x0 - 1 + px) < (unsigned)p.W;
                     uint2 ph, plo;
@@ -881,13 +909,16 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                         const int cl = H3P_EPI_CL(mg);
                         if (mg + 1 < 8) {
                             H3P_EPI_READS(ec[(mg + 1) & 1], H3P_EPI_CL(mg + 1));
-                            LM_LDS_WAIT3(3, ec[mg & 1][0], ec[mg & 1][1], ec[mg & 1][2]);
+                            H3P_EPI_WAIT(true, ec[mg & 1]);
                         } else {
-                            LM_LDS_WAIT3(0, ec[mg & 1][0], ec[mg & 1][1], ec[mg & 1][2]);
+                            H3P_EPI_WAIT(false, ec[mg & 1]);
                         }
-                        const float4 bias = as_float4(ec[mg & 1][0]), s = as_float4(ec[mg & 1][1]), sh = as_float4(ec[mg & 1][2]);
+                        const float4 bias = as_float4(ec[mg & 1][0]);
                         float bb[4] = {bias.x, bias.y, bias.z, bias.w};
+#if !LM_H3_FOLD_SCALE
+                        const float4 s = as_float4(ec[mg & 1][1]), sh = as_float4(ec[mg & 1][2]);
                         const float ss[4] = {s.x, s.y, s.z, s.w}, tt[4] = {sh.x, sh.y, sh.z, sh.w};
+#endif
                         if (border) {
                             const float4 c = cb[mg];
                             bb[0] -= c.x;
@@ -899,7 +930,11 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             float t = fmaf(accm[mt][nt][4 * g4 + k], p.acc_scale, bb[k]);
+#if LM_H3_FOLD_SCALE
+                            if (bn) t = fmaxf(t, 0.f);
+#else
                             if (bn) t = fmaf(fmaxf(t, 0.f), ss[k], tt[k]);
+#endif
                             v[k] = t;
                         }
 #pragma unroll
@@ -1017,12 +1052,15 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                     const int cl = H3P_EPI_CL(mg);  // first of 4 consecutive local output channels
                     if (g4 + 1 < 4) {
                         H3P_EPI_READS(ec[(g4 + 1) & 1], H3P_EPI_CL(mg + 1));
-                        LM_LDS_WAIT3(3, ec[g4 & 1][0], ec[g4 & 1][1], ec[g4 & 1][2]);
+                        H3P_EPI_WAIT(true, ec[g4 & 1]);
                     } else {
-                        LM_LDS_WAIT3(0, ec[g4 & 1][0], ec[g4 & 1][1], ec[g4 & 1][2]);
+                        H3P_EPI_WAIT(false, ec[g4 & 1]);
                     }
-                    const float4 bias = as_float4(ec[g4 & 1][0]), s = as_float4(ec[g4 & 1][1]), sh = as_float4(ec[g4 & 1][2]);
+                    const float4 bias = as_float4(ec[g4 & 1][0]);
+#if !LM_H3_FOLD_SCALE
+                    const float4 s = as_float4(ec[g4 & 1][1]), sh = as_float4(ec[g4 & 1][2]);
                     const float ss[4] = {s.x, s.y, s.z, s.w}, tt[4] = {sh.x, sh.y, sh.z, sh.w};
+#endif
                     if (g4 + 1 < 4) load_cb(g4 + 1);
                     float v[2][4];
 #pragma unroll
@@ -1038,7 +1076,11 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             float t = fmaf(accm[mt][nt][4 * g4 + k], p.acc_scale, bb[k]);
+#if LM_H3_FOLD_SCALE
+                            if (bn) t = fmaxf(t, 0.f);
+#else
                             if (bn) t = fmaf(fmaxf(t, 0.f), ss[k], tt[k]);
+#endif
                             v[nt][k] = t;
                         }
                         uint2 ph, plo;

@@ -44,5 +44,8 @@ hipError_t launch_reorient(const ReorientParams& p, hipStream_t stream);
 hipError_t launch_bodymask_bbox(const BodyMaskParams& p, hipStream_t stream);
 hipError_t launch_resample_norm(const ResampleParams& p, hipStream_t stream);
 hipError_t launch_reshape_mask(const ReshapeParams& p, hipStream_t stream);
+// Extent of the non-zero labels of vol [N][H][W] along the two slow axes: ext[4] = {z0, z1, y0, y1} half-open (z0 >= z1: the
+// volume is all zero).  lm_apply_host copies only that slab back to a zero-filled result array (a lung mask is mostly background).
+hipError_t launch_label_extent(const uint8_t* vol, int N, int H, int W, int* ext_dev, hipStream_t stream);
 
 }  // namespace lm

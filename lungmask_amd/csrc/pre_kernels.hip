@@ -437,6 +437,55 @@ hipError_t launch_resample_norm(const ResampleParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// one wave per image row: 16 bytes per lane and step, a ballot per step; rows with a label raise the extent
+__global__ __launch_bounds__(256) void label_extent_init_kernel(int* ext, int N, int H) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        ext[0] = N;
+        ext[1] = 0;
+        ext[2] = H;
+        ext[3] = 0;
+    }
+}
+__global__ __launch_bounds__(256) void label_extent_kernel(const uint8_t* __restrict__ vol, int N, int H, int W, int* ext) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long rows = (long long)N * H;
+    int zlo = N, zhi = 0, ylo = H, yhi = 0;
+    for (long long r = (long long)blockIdx.x * 4 + wv; r < rows; r += (long long)gridDim.x * 4) {
+        const uint8_t* row = vol + (size_t)r * W;
+        bool any = false;
+        if ((W & 15) == 0 && (reinterpret_cast<uintptr_t>(row) & 15) == 0) {
+            for (int x = lane * 16; x < W; x += 64 * 16) {
+                const uint4 v = *reinterpret_cast<const uint4*>(row + x);
+                any |= (v.x | v.y | v.z | v.w) != 0u;
+            }
+        } else {
+            for (int x = lane; x < W; x += 64) any |= row[x] != 0;
+        }
+        if (__any(any)) {
+            const int z = (int)(r / H), y = (int)(r - (long long)z * H);
+            zlo = min(zlo, z);
+            zhi = max(zhi, z + 1);
+            ylo = min(ylo, y);
+            yhi = max(yhi, y + 1);
+        }
+    }
+    if (lane == 0 && zhi > zlo) {
+        atomicMin(&ext[0], zlo);
+        atomicMax(&ext[1], zhi);
+        atomicMin(&ext[2], ylo);
+        atomicMax(&ext[3], yhi);
+    }
+}
+
+hipError_t launch_label_extent(const uint8_t* vol, int N, int H, int W, int* ext_dev, hipStream_t stream) {
+    LM_LAUNCH(label_extent_init_kernel, dim3(1), dim3(256), 0, stream, ext_dev, N, H);
+    if (N <= 0 || H <= 0 || W <= 0) return hipGetLastError();
+    const long long rows = (long long)N * H;
+    const unsigned blocks = (unsigned)std::min<long long>((rows + 3) / 4, 256 * 16);
+    LM_LAUNCH(label_extent_kernel, dim3(blocks), dim3(256), 0, stream, vol, N, H, W, ext_dev);
+    return hipGetLastError();
+}
+
 hipError_t launch_reshape_mask(const ReshapeParams& p, hipStream_t stream) {
     if (p.N <= 0) return hipSuccess;
     if (p.W % 4 == 0 && p.W <= RS_MAXW && p.MW < 32768 && p.N < 65536 && (reinterpret_cast<uintptr_t>(p.out) & 3) == 0) {

@@ -363,6 +363,7 @@ class LMInferer:
                 return out
             return np.ascontiguousarray(back)
         if axes == (0, 1, 2) and not any(flips):
+            own = out is None  # an array of this object's: its old contents are nobody's (lm_apply_host_ex, LM_APPLY_OUT_SCRATCH)
             if out is None and self.reuse_output:
                 if self._out is None or self._out.shape != tuple(inimg_raw.shape):
                     self._out = np.empty(inimg_raw.shape, dtype=np.uint8)
@@ -371,7 +372,7 @@ class LMInferer:
                 out = self._result_array(inimg_raw.shape)
             # (the labels land in `out` / the result array straight from the device: no further host copy)
             return self.engine.apply(0, inimg_raw, fill_slot=self.fill_slot, batch_size=self.batch_size,
-                                     volume_postprocessing=self.volume_postprocessing, out=out)
+                                     volume_postprocessing=self.volume_postprocessing, out=out, out_scratch=own)
         else:
             from . import volume_io
 

@@ -87,6 +87,10 @@ inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { m
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t = nullptr) {
+    for (size_t r = 0; r < height; ++r) memcpy(static_cast<char*>(d) + r * dpitch, static_cast<const char*>(s) + r * spitch, width);
+    return hipSuccess;
+}
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipStreamDefault = 0, hipDeviceAttributeMultiprocessorCount = 1 };
 inline hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 0; *greatest = 0; return hipSuccess; }

@@ -570,3 +570,31 @@ def test_lminferer_over_several_engines_in_one_process(gpu_engine, fused):
             img = volume_io.Volume(np.ascontiguousarray(volume_io.apply_transform(vol, *volume_io.inverse_transform(axes, flips))), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0), direction)
             assert np.array_equal(inf.apply(img), single.apply(img))
         inf.close()
+
+
+def test_apply_host_scratch_output_copies_back_only_the_labelled_slab(gpu_engine):
+    """lm_apply_host_ex(LM_APPLY_OUT_SCRATCH) -- what LMInferer.apply uses for the result arrays it allocates itself: the array is
+    zero-filled on the helper thread while the network runs and only the slices x rows that carry a label come back (one strided
+    copy).  Same labels as the plain call whatever was in the array before: a volume whose lungs touch the first and last slice, an
+    air-only volume (nothing to copy), a single slice, a width that is not a multiple of 16, a float volume; and through LMInferer."""
+    from lungmask_amd.mask import LMInferer
+
+    sd = uo.synthetic_state_dict(3, head="lunglike")
+    gpu_engine.load_state_dict(0, sd)
+    rng = np.random.default_rng(4)
+    cases = [po.phantom(300, 512, 512, z0=130, z1=175), po.phantom(45, 512, 512, seed=5), np.full((24, 512, 512), -1000, np.int16),
+             po.phantom(300, 512, 512, z0=150, z1=151), po.phantom(23, 300, 420, seed=6), po.phantom(21, 512, 512, seed=8).astype(np.float32)]
+    for vol in cases:
+        expect = gpu_engine.apply(0, vol, out=np.empty(vol.shape, np.uint8))
+        junk = rng.integers(0, 256, vol.shape, dtype=np.uint8)
+        got = gpu_engine.apply(0, vol, out=junk, out_scratch=True)
+        assert got is junk and np.array_equal(got, expect), (vol.shape, int((got != expect).sum()))
+        assert np.array_equal(gpu_engine.apply(0, vol), expect)  # (an array allocated by the binding is scratch by definition)
+    inf = LMInferer(state_dict=sd, engine=gpu_engine)
+    vol = cases[0]
+    expect = gpu_engine.apply(0, vol, out=np.empty(vol.shape, np.uint8))
+    first = inf.apply(vol)
+    second = inf.apply(vol[::-1].copy())  # another result block ...
+    del second
+    third = inf.apply(vol)  # ... handed out again with the reversed volume's labels in it
+    assert np.array_equal(first, expect) and np.array_equal(third, expect)
