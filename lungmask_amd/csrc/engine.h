@@ -129,15 +129,17 @@ struct HostBuf {
 };
 
 struct PostWorkspace {
-    HostBuf h_area, h_labval, h_recs, h_scalars;
+    HostBuf h_area, h_labval, h_recs, h_scalars, h_rbox, h_pairs;
     // what the previous volume needed: sizes the tables and the speculative read-back of the next one (postprocess)
     int last_regions = 0;
-    unsigned last_records = 0;
+    unsigned last_records = 0, last_pairs = 0;
     DevBuf parent, ids, rank, bgparent, blockcnt, area, labval, recs, lut, mapped, bg, out, scalars, bbox;
+    DevBuf rbox, pairs;  // region-graph form of the second labelling: bounding box per region, diagonal adjacency pairs
     void release() {
         parent.release(); ids.release(); rank.release(); bgparent.release(); blockcnt.release(); area.release(); labval.release();
         recs.release(); lut.release(); mapped.release(); bg.release(); out.release(); scalars.release(); bbox.release();
-        h_area.release(); h_labval.release(); h_recs.release(); h_scalars.release();
+        rbox.release(); pairs.release();
+        h_area.release(); h_labval.release(); h_recs.release(); h_scalars.release(); h_rbox.release(); h_pairs.release();
     }
 };
 

@@ -405,6 +405,28 @@ __device__ __forceinline__ void lm_fma_f32_single(float& acc, float x, float w) 
 #endif
 }
 
+// DPP row broadcast: every lane reads `w` from lane K of its own row of 16 lanes (row_newbcast).  acc += w[row lane K] * x, and the
+// plain move.  A wave-uniform table of up to 16 values therefore lives in ONE register (lane k of every row holds value k) and
+// costs no LDS read, no scalar register and no extra instruction at the point of use.  All lanes of the row must be active.
+template <int K>
+__device__ __forceinline__ void lm_fmac_rowbcast(float& acc, float w, float x) {
+#ifdef LM_EMU_BUILD
+    acc = fmaf(__shfl(w, ((int)(lm_emu::linear_tid() & 63) & ~15) | K), x, acc);
+#else
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "v"(x), "n"(K));
+#endif
+}
+template <int K>
+__device__ __forceinline__ float lm_mov_rowbcast(float w) {
+#ifdef LM_EMU_BUILD
+    return __shfl(w, ((int)(lm_emu::linear_tid() & 63) & ~15) | K);
+#else
+    float r = 0.f;
+    asm("v_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(w), "n"(K));
+    return r;
+#endif
+}
+
 // v_permlane32_swap_b32: a[lanes 32..63] <-> b[lanes 0..31] (gfx950).  In the conv epilogue lanes l and l + 32 hold the two 4-channel
 // halves of the same pixel's 8-channel group: after swapping (hi, lo) word by word, lane l owns all eight hi halves and lane l + 32
 // all eight lo halves -- one 16-byte store each instead of two 8-byte pieces staged through LDS.

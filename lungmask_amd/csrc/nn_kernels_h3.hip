@@ -391,6 +391,16 @@ __device__ __forceinline__ float4 as_float4(const lm_h16x8& v) {
 namespace {
 constexpr int FC_PW = 36, FC_PH = 20, FC_PATCH = FC_PW * FC_PH;
 constexpr int FC_CONST = 9 * 64 + 64 + 64;  // w[9][64] | bias[64] | bn scale[64]
+// LM_PROD_DPP (needs LM_H3_FOLD_SCALE: no scale row): the constants live in LDS as 10 rows (taps 0..8, bias) of 64 + 4 floats -- the
+// padding puts the 16-byte pieces of consecutive rows 4 banks apart -- and a half-task fetches ALL its 40 constants with ONE
+// ds_read_b128: lane l reads row min(l & 15, 9) at its 4 channels, so register j of the result holds, in lane k of every row of 16
+// lanes, constant k of channel j, and the multiply-adds take it from there by DPP row broadcast (lm_fmac_rowbcast).  Ten broadcast
+// ds_read_b128 per half-task (1 KiB of LDS bandwidth each) become one.
+#ifndef LM_PROD_DPP
+#define LM_PROD_DPP (LM_H3_FOLD_SCALE ? 1 : 0)
+#endif
+constexpr int FC_ROW = 68;
+static_assert(!LM_PROD_DPP || (LM_H3_FOLD_SCALE && 10 * FC_ROW <= FC_CONST), "the DPP producer's constant table");
 constexpr int FC_TASKS = 18 * 34 * 2;
 
 }  // namespace
@@ -540,7 +550,8 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
     int pr_c0 = 0, pr_y0 = 0, pr_x0 = 0, pr_par = 0;
     char* pr_buf = lds;
     lm_f32x2 pr_x[5];      // a pixel's 3 x 3 input neighbourhood (taps 2 i, 2 i + 1), kept for the half-tasks that share it
-    lm_f32x4 pr_w[5];      // weight / constant reads in flight (issued one micro-step ahead of their use)
+    lm_f32x4 pr_w[LM_PROD_DPP ? 1 : 5];  // weight / constant reads in flight (issued one micro-step ahead of their use)
+    float pr_s[4] = {0.f, 0.f, 0.f, 0.f};  // LM_PROD_DPP: the half-task's four channel accumulators as single registers
     lm_f32x2 pr_a[2];      // the half-task's four channel accumulators
     unsigned pr_max = 0u;  // f16 range guard of the values the producer writes
     // this thread's two halo pixels (item invariant): py | px << 8, byte offset of the pixel's group-0 hi slot in a chunk image
@@ -548,7 +559,11 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
     if constexpr (PROD == 1) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+#if LM_PROD_DPP  // round 2: group g = tid / 112 (seven whole rows of 16 lanes per group: the constants are per row), pixel 512 + tid % 112
+            const int pxl = i == 0 ? tid : min(512 + (tid % 112), 611);
+#else
             const int pxl = i == 0 ? tid : 512 + (tid % 100);
+#endif
             const int py = pxl / 34, px = pxl - 34 * py;
             pr_pyx[i] = py | (px << 8);
             pr_woff[i] = pxl * 64 + (((px >> 2) & 3) << 4);  // logical slot 0 at physical slot (px >> 2) & 3; slot s at ^ (s << 4)
@@ -617,6 +632,71 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
             const int r = hs >> 1, half = hs & 1, pi = r == 2 ? 1 : 0;
             if (!pr_on) return;
             LM_SCHED_FENCE();
+#if LM_PROD_DPP
+            if (r < 2 || wave < 4) {  // (whole waves: a row broadcast needs its source lanes active; idle lanes compute and do not store)
+                const int grp = r == 2 ? (tid >= 112 ? 1 : 0) : r;
+                const int py = pr_pyx[pi] & 0xff, px = pr_pyx[pi] >> 8;
+                float& a0 = pr_s[0];
+                float& a1 = pr_s[1];
+                float& a2 = pr_s[2];
+                float& a3 = pr_s[3];
+                lm_f32x4& W = pr_w[0];
+#define PROD_TAP(K, X)                          \
+    do {                                        \
+        lm_fmac_rowbcast<K>(a0, W[0], (X));     \
+        lm_fmac_rowbcast<K>(a1, W[1], (X));     \
+        lm_fmac_rowbcast<K>(a2, W[2], (X));     \
+        lm_fmac_rowbcast<K>(a3, W[3], (X));     \
+    } while (0)
+                if (m == 0) {
+                    if (half == 0 && r != 1) {  // the pixel's 3 x 3 input neighbourhood (the patch starts one more pixel up and left)
+                        const float* xp = fcx + pr_par * FC_PATCH + py * FC_PW + px;
+                        pr_x[0] = lm_f32x2{xp[0], xp[1]};
+                        pr_x[1] = lm_f32x2{xp[2], xp[FC_PW]};
+                        pr_x[2] = lm_f32x2{xp[FC_PW + 1], xp[FC_PW + 2]};
+                        pr_x[3] = lm_f32x2{xp[2 * FC_PW], xp[2 * FC_PW + 1]};
+                        pr_x[4] = lm_f32x2{xp[2 * FC_PW + 2], 0.f};
+                    }
+                    // all 40 constants of this half-task's four channels: lane l fetches row min(l & 15, 9)
+                    W = *reinterpret_cast<const lm_f32x4*>(fcc + min(lane & 15, 9) * FC_ROW + pr_c0 + 8 * grp + 4 * half);
+                } else if (m == 1) {
+                    // first_conv_h3_kernel's chain: bias, then taps 0..8
+                    a0 = lm_mov_rowbcast<9>(W[0]);
+                    a1 = lm_mov_rowbcast<9>(W[1]);
+                    a2 = lm_mov_rowbcast<9>(W[2]);
+                    a3 = lm_mov_rowbcast<9>(W[3]);
+                    PROD_TAP(0, pr_x[0][0]);
+                    PROD_TAP(1, pr_x[0][1]);
+                } else if (m == 2) {
+                    PROD_TAP(2, pr_x[1][0]);
+                    PROD_TAP(3, pr_x[1][1]);
+                } else if (m == 3) {
+                    PROD_TAP(4, pr_x[2][0]);
+                    PROD_TAP(5, pr_x[2][1]);
+                } else if (m == 4) {
+                    PROD_TAP(6, pr_x[3][0]);
+                    PROD_TAP(7, pr_x[3][1]);
+                } else {
+                    PROD_TAP(8, pr_x[4][0]);
+                    const float v0 = fmaxf(a0, 0.f), v1 = fmaxf(a1, 0.f), v2 = fmaxf(a2, 0.f), v3 = fmaxf(a3, 0.f);
+                    // zero padding of THIS conv: halo pixels outside the image are 0 (one unsigned compare per axis)
+                    const bool inside = (unsigned)(pr_y0 - 1 + py) < (unsigned)p.H && (unsigned)(pr_x0 - 1 + px) < (unsigned)p.W;
+                    uint2 ph, plo;
+                    lm_split4(v0, v1, v2, v3, &ph, &plo);
+                    if (!inside) {
+                        ph.x = ph.y = 0u;
+                        plo.x = plo.y = 0u;
+                    }
+                    if (r < 2 || (tid < 224 && (tid % 112) < 100)) {
+                        pr_max = lm_pk_absmax_u16(lm_pk_absmax_u16(pr_max, ph.x), ph.y);
+                        const int off = (pr_woff[pi] ^ (grp << 5)) + half * 8;  // group g: logical slots 2 g (hi), 2 g + 1 (lo)
+                        *reinterpret_cast<uint2_a*>(pr_buf + off) = ph;
+                        *reinterpret_cast<uint2_a*>(pr_buf + (off ^ 16)) = plo;
+                    }
+                }
+#undef PROD_TAP
+            }
+#else
             if (r < 2 || tid < 200) {
                 const int grp = r == 2 ? (tid >= 100 ? 1 : 0) : r;
                 const int py = pr_pyx[pi] & 0xff, px = pr_pyx[pi] >> 8;
@@ -716,6 +796,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                     *reinterpret_cast<uint2_a*>(pr_buf + (off ^ 16)) = plo;
                 }
             }
+#endif
             LM_SCHED_FENCE();
         }
     };
@@ -755,7 +836,11 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
 #pragma unroll
     for (int k = 0; k < N_SLOTS; ++k) dma_slot(k);
     if constexpr (PROD == 1) {  // the first item's chunk 0 is computed here, with nothing to run beside
+#if LM_PROD_DPP
+        for (int i = tid; i < 640; i += 512) fcc[(i >> 6) * FC_ROW + (i & 63)] = p.fc_c[i];
+#else
         for (int i = tid; i < FC_CONST; i += 512) fcc[i] = p.fc_c[i];
+#endif
         fc_patch_dma(b, y0, x0, 0);
         lm_barrier_dma();
 #pragma unroll

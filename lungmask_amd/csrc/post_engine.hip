@@ -141,6 +141,60 @@ void replay_merge(int R, const int* area, const uint8_t* lv, const BoundaryRec* 
     }
 }
 
+// utils.py:355-356 / :390-404 on the region graph: the components of the mapped volume are unions of first-pass regions that are
+// 26-adjacent and carry the same mapped label (the 6-adjacency is in the boundary records, the diagonal rest in `pairs`).  For
+// every label the largest component is kept (area; on ties the component whose first voxel comes LAST in raster order -- regions
+// are numbered by their first voxel, so that is the component with the largest smallest id: the rule of component_max's key).
+// keeplut[region] = its label when the region belongs to its label's kept component, else 0; lbox[label] = that component's box.
+static void graph_components(int R, const int* area, const std::vector<uint8_t>& lut, const BoundaryRec* recs, size_t nrecs, const unsigned long long* pairs,
+                             size_t npairs, const int* rbox, int dropped_label, std::vector<uint8_t>& keeplut, int lbox[256][6], bool kept[256]) {
+    std::vector<int> uf(R + 1);
+    std::iota(uf.begin(), uf.end(), 0);
+    auto find = [&](int a) {
+        while (uf[a] != a) {
+            uf[a] = uf[uf[a]];
+            a = uf[a];
+        }
+        return a;
+    };
+    auto unite = [&](int a, int b) {  // the root of a set is its SMALLEST id (= the region with the component's first voxel)
+        if (a < 1 || b < 1 || a > R || b > R || !lut[a] || lut[a] != lut[b]) return;
+        a = find(a);
+        b = find(b);
+        if (a == b) return;
+        if (a < b) uf[b] = a;
+        else uf[a] = b;
+    };
+    for (size_t j = 0; j < nrecs; ++j)
+        for (int k = 0; k < 6 && recs[j].nb[k]; ++k) unite(recs[j].atom, recs[j].nb[k]);
+    for (size_t j = 0; j < npairs; ++j) unite((int)(pairs[j] >> 32), (int)(pairs[j] & 0xffffffffull));
+    std::vector<long long> carea(R + 1, 0);
+    for (int a = 1; a <= R; ++a)
+        if (lut[a]) carea[find(a)] += area[a];
+    int best[256];
+    for (int i = 0; i < 256; ++i) {
+        best[i] = 0;
+        kept[i] = false;
+        lbox[i][0] = lbox[i][1] = lbox[i][2] = 0x7fffffff;
+        lbox[i][3] = lbox[i][4] = lbox[i][5] = -1;
+    }
+    for (int a = 1; a <= R; ++a) {
+        if (!lut[a] || uf[a] != a) continue;
+        const int L = lut[a], b = best[L];
+        if (!b || carea[a] > carea[b] || (carea[a] == carea[b] && a > b)) best[L] = a;
+    }
+    keeplut.assign((size_t)R + 1, 0);
+    for (int a = 1; a <= R; ++a) {
+        const int L = lut[a];
+        if (!L || L == dropped_label || find(a) != best[L]) continue;
+        keeplut[a] = (uint8_t)L;
+        kept[L] = true;
+        const int* b = rbox + 6 * (size_t)a;
+        for (int k = 0; k < 3; ++k) lbox[L][k] = std::min(lbox[L][k], b[k]);
+        for (int k = 3; k < 6; ++k) lbox[L][k] = std::max(lbox[L][k], b[k]);
+    }
+}
+
 int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spare_p, int n_spare, int skip_below, int range_slot, bool* range_tripped) {
     if (range_tripped) *range_tripped = false;
     if (N <= 0 || H <= 0 || W <= 0) return LM_OK;
@@ -178,14 +232,21 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
     unsigned* count_dev = ws.scalars.as<unsigned>() + 1;
     unsigned long long* best_dev = reinterpret_cast<unsigned long long*>(ws.scalars.as<char>() + 1024);
 
+    // The second labelling (step 5) on the REGION GRAPH instead of the voxels (N > 1; LM_POST_GRAPH=0: the voxel form, A/B and test
+    // hook): part 1 also delivers every region's bounding box and the pairs of regions that only touch diagonally, the host finds
+    // the kept component of every label on the graph, and apply_lut / the second 26-connected labelling / component_max / the
+    // bounding-box pass and their read-back do not run at all.  Nothing reads flat parents then, so the labelling skips that pass.
+    static const bool graph_ok = [] { const char* v = getenv("LM_POST_GRAPH"); return !(v && v[0] == '0'); }();
+    const bool graph = graph_ok && N > 1;
+    unsigned* pcount_dev = ws.scalars.as<unsigned>() + 3;
     // ---- (1) skimage.measure.label (26-connected, multi-label), ids in raster order        utils.py:293
     {
         ProfScope ps(e, "post_ccl26_multilabel", (double)nvox * 13);
-        LM_K(ccl_label(lab, parent, d, true, s));
+        LM_K(ccl_label(lab, parent, d, true, s, !graph));
     }
     {
         ProfScope ps(e, "post_rank_relabel", (double)nvox * 16);
-        LM_K(ccl_rank(parent, ws.rank.as<int>(), ids, ws.blockcnt.as<int>(), total_dev, nvox, s));
+        LM_K(ccl_rank(parent, ws.rank.as<int>(), ids, ws.blockcnt.as<int>(), total_dev, nvox, s, !graph));
     }
     // ---- (2)-(3) run BEFORE the host knows this volume's region count: the tables are sized from the previous volume (what it
     // needed + a margin; the kernels ignore ids / records beyond the capacity and the host repeats a pass whose guess was too
@@ -200,8 +261,9 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
     static const bool tiny = [] { const char* v = getenv("LM_POST_SMALL_TABLES"); return v && v[0] == '1'; }();
     int rcap = tiny ? 8 : std::max(16384, ws.last_regions + ws.last_regions / 2 + 1024);
     unsigned cap = tiny ? 8u : (unsigned)std::min<size_t>(nvox, std::max<size_t>(ws.recs.cap / sizeof(BoundaryRec), 1u << 20));
+    unsigned pcap = tiny ? 8u : (unsigned)std::max<size_t>(ws.pairs.cap / 8, 1u << 18);
     int R = 0;
-    unsigned nrec = 0;
+    unsigned nrec = 0, npair = 0;
     std::vector<uint8_t> lut(1, 0);
     const int* area = nullptr;
     const uint8_t* lv = nullptr;
@@ -214,7 +276,12 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
         // ---- (2) regionprops: area + label value                                           utils.py:298
         LM_HIP(hipMemsetAsync(ws.area.p, 0, ((size_t)rcap + 1) * 4, s));
         LM_HIP(hipMemsetAsync(ws.labval.p, 0, (size_t)rcap + 1, s));
-        {
+        if (graph) {
+            LM_TRY(ws.rbox.reserve(((size_t)rcap + 1) * 6 * 4));
+            LM_TRY(ws.pairs.reserve((size_t)pcap * 8));
+            ProfScope ps(e, "post_region_stats", (double)nvox * 5);
+            LM_K(region_stats_box(ids, lab, ws.area.as<int>(), ws.labval.as<uint8_t>(), ws.rbox.as<int>(), d, s, rcap));
+        } else {
             ProfScope ps(e, "post_region_stats", (double)nvox * 5);
             LM_K(region_stats(ids, lab, ws.area.as<int>(), ws.labval.as<uint8_t>(), nvox, s, rcap));
         }
@@ -224,13 +291,25 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
             ProfScope ps(e, "post_boundary_records", (double)nvox * 4);
             LM_K(boundary_records(ids, d, ws.recs.as<BoundaryRec>(), count_dev, cap, s));
         }
+        if (graph) {  // regions that touch only diagonally (the rest of the 26-adjacency)
+            LM_HIP(hipMemsetAsync(pcount_dev, 0, sizeof(unsigned), s));
+            ProfScope ps(e, "post_diag_pairs", (double)nvox * 2);
+            LM_K(diag_pairs(lab, ids, d, ws.pairs.as<unsigned long long>(), pcount_dev, pcap, s));
+        }
         // speculative read-back
         const size_t g_r = tiny ? (size_t)std::min(rcap, 4) : (size_t)std::min(rcap, std::max(4096, ws.last_regions + ws.last_regions / 4 + 256));
         const size_t g_n = tiny ? std::min<size_t>(cap, 4) : std::min<size_t>(cap, std::max<size_t>(32768, (size_t)ws.last_records + ws.last_records / 4 + 1024));
         LM_TRY(ws.h_area.reserve((g_r + 1) * 4));
         LM_TRY(ws.h_labval.reserve(g_r + 1));
         LM_TRY(ws.h_recs.reserve(g_n * sizeof(BoundaryRec)));
-        LM_HIP(hipMemcpyAsync(ws.h_scalars.p, total_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, s));  // total_dev, count_dev are neighbours
+        const size_t g_p = tiny ? std::min<size_t>(pcap, 4) : std::min<size_t>(pcap, std::max<size_t>(16384, (size_t)ws.last_pairs + ws.last_pairs / 4 + 1024));
+        if (graph) {
+            LM_TRY(ws.h_rbox.reserve((g_r + 1) * 6 * 4));
+            LM_TRY(ws.h_pairs.reserve(g_p * 8));
+            LM_HIP(hipMemcpyAsync(ws.h_rbox.p, ws.rbox.p, (g_r + 1) * 6 * 4, hipMemcpyDeviceToHost, s));
+            LM_HIP(hipMemcpyAsync(ws.h_pairs.p, ws.pairs.p, g_p * 8, hipMemcpyDeviceToHost, s));
+        }
+        LM_HIP(hipMemcpyAsync(ws.h_scalars.p, total_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, s));  // total_dev, count_dev, (fusion's max), pcount_dev
         if (want_range && attempt == 0) LM_HIP(hipMemcpyAsync(e->range_flag_host, e->range_flag, sizeof(unsigned), hipMemcpyDeviceToHost, s));
         LM_HIP(hipMemcpyAsync(ws.h_area.p, ws.area.p, (g_r + 1) * 4, hipMemcpyDeviceToHost, s));
         LM_HIP(hipMemcpyAsync(ws.h_labval.p, ws.labval.p, g_r + 1, hipMemcpyDeviceToHost, s));
@@ -244,10 +323,19 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
         }
         R = hs[0];
         nrec = (unsigned)hs[1];
-        if (R > rcap || nrec > cap) {  // rare: a table was too small -- grow and repeat both passes
+        npair = graph ? (unsigned)hs[3] : 0u;
+        if (R > rcap || nrec > cap || npair > pcap) {  // rare: a table was too small -- grow and repeat the passes
             rcap = std::max(rcap, R);
             cap = std::max(cap, nrec);
+            pcap = std::max(pcap, npair);
             continue;
+        }
+        if (graph && ((size_t)R > g_r || npair > g_p)) {
+            LM_TRY(ws.h_rbox.reserve(((size_t)R + 1) * 6 * 4));
+            LM_TRY(ws.h_pairs.reserve(std::max<size_t>((size_t)npair * 8, 64)));
+            LM_HIP(hipMemcpyAsync(ws.h_rbox.p, ws.rbox.p, ((size_t)R + 1) * 6 * 4, hipMemcpyDeviceToHost, s));
+            if (npair) LM_HIP(hipMemcpyAsync(ws.h_pairs.p, ws.pairs.p, (size_t)npair * 8, hipMemcpyDeviceToHost, s));
+            if (!((size_t)R > g_r || nrec > g_n)) LM_HIP(hipStreamSynchronize(s));
         }
         if ((size_t)R > g_r || nrec > g_n) {  // the tables are complete on the device, the guess of what to fetch was short (first volume)
             LM_TRY(ws.h_area.reserve(((size_t)R + 1) * 4));
@@ -262,6 +350,7 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
     }
     ws.last_regions = R;
     ws.last_records = nrec;
+    ws.last_pairs = npair;
     info.regions = R;
     info.boundary_records = nrec;
     area = ws.h_area.as<int>();
@@ -287,6 +376,49 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
                 if (area[a] > 0) smallest = std::min<int>(smallest, lut[a]);
             }
         if (R > 0 && nonzero == (long long)nvox && smallest < 256) dropped_label = smallest;
+    }
+    if (graph) {
+        // ---- (5) on the region graph: kept component of every label, its bounding box; then per label the hole fill on its box
+        std::vector<uint8_t> keeplut;
+        int lbox[256][6];
+        bool kept[256];
+        graph_components(R, area, lut, recs, nrec, ws.h_pairs.as<unsigned long long>(), npair, ws.h_rbox.as<int>(), dropped_label, keeplut, lbox, kept);
+        const double t_graph = ms_now();
+        keeplut.resize(std::max<size_t>(keeplut.size(), 1), 0);
+        LM_TRY(ws.lut.reserve(keeplut.size()));
+        LM_HIP(hipMemcpyAsync(ws.lut.p, keeplut.data(), keeplut.size(), hipMemcpyHostToDevice, s));
+        uint8_t* out = ws.out.as<uint8_t>();
+        LM_HIP(hipMemsetAsync(out, 0, nvox, s));
+        const uint8_t* kl = ws.lut.as<uint8_t>();
+        for (int label = 1; label < 256; ++label) {
+            if (!kept[label]) continue;
+            const int* bb = lbox[label];
+            Box box;
+            box.z0 = std::max(bb[0] - 1, 0);
+            box.y0 = std::max(bb[1] - 1, 0);
+            box.x0 = std::max(bb[2] - 1, 0) & ~3;  // x extent widened to multiples of 4 (a larger box is as exact): the row-wise labelling kernel applies
+            box.d = Dims{std::min(bb[3] + 2, N) - box.z0, std::min(bb[4] + 2, H) - box.y0, std::min((bb[5] + 2 + 3) & ~3, W) - box.x0};
+            const size_t nbox = box.d.nvox();
+            LM_K(complement_of_lut_box(ids, kl, (uint8_t)label, d, box, ws.bg.as<uint8_t>(), s));
+            {
+                ProfScope ps(e, "post_ccl6_background", (double)nbox * 9);
+                LM_K(ccl_label(ws.bg.as<uint8_t>(), ws.bgparent.as<int>(), box.d, false, s));
+            }
+            LM_K(flag_face_components(ws.bgparent.as<int>(), ws.rank.as<int>() /* free since the numbering */, box.d, s));
+            {
+                ProfScope ps(e, "post_fill_write", (double)nbox * 13);
+                LM_K(fill_write_lut_box(ids, kl, ws.bgparent.as<int>(), ws.rank.as<int>(), (uint8_t)label, out, d, box, s));
+            }
+        }
+        LM_HIP(hipMemcpyAsync(lab, out, nvox, hipMemcpyDeviceToDevice, s));
+        // (keeplut lives on this stack frame until the copy above has read it: pageable source, the call returns after staging)
+        if (timing) {
+            const double t_enq3 = ms_now();
+            (void)hipStreamSynchronize(s);
+            fprintf(stderr, "lm_postprocess (region graph): part 1 enqueued %.3f | read-back done %.3f | merge replay done %.3f | components on the graph %.3f | "
+                    "hole fills enqueued %.3f | all done %.3f ms (%d regions, %u records, %u diagonal pairs)\n", t_enq1, t_sync1, t_replay, t_graph, t_enq3, ms_now(), R, nrec, npair);
+        }
+        return LM_OK;
     }
     LM_TRY(ws.lut.reserve(lut.size()));
     LM_HIP(hipMemcpyAsync(ws.lut.p, lut.data(), lut.size(), hipMemcpyHostToDevice, s));

@@ -23,14 +23,23 @@ struct BoundaryRec {
 
 // ---- connected components (union-find on an int32 parent volume; root = first voxel in raster order)
 // lab: u8 volume; foreground = non-zero; voxels are connected when adjacent AND equal.
-hipError_t ccl_label(const uint8_t* lab, int* parent, Dims d, bool conn26, hipStream_t s);
+// flatten = false: the forest is left as the hooking built it (roots are roots: parent[v] == v); ccl_rank(flat = false) then walks
+// the chains itself, which spares a read-modify-write pass over the parent volume when nothing else needs flat parents.
+hipError_t ccl_label(const uint8_t* lab, int* parent, Dims d, bool conn26, hipStream_t s, bool flatten = true);
 // Dense ids in raster order of each component's first voxel (== skimage.measure.label numbering).
 // blockcnt: scratch of >= nblocks(nvox)+1 ints.  total_dev receives the number of components.
 size_t rank_blocks(size_t nvox);
-hipError_t ccl_rank(const int* parent, int* rank, int* ids, int* blockcnt, int* total_dev, size_t nvox, hipStream_t s);
+hipError_t ccl_rank(const int* parent, int* rank, int* ids, int* blockcnt, int* total_dev, size_t nvox, hipStream_t s, bool flat = true);
 hipError_t region_stats(const int* ids, const uint8_t* lab, int* area, uint8_t* labval, size_t nvox, hipStream_t s, int cap = 0x7fffffff);
 hipError_t boundary_records(const int* ids, Dims d, BoundaryRec* recs, unsigned* count_dev, unsigned cap, hipStream_t s);
 hipError_t apply_lut(const int* ids, const uint8_t* lut, uint8_t* out, size_t nvox, hipStream_t s);
+
+// ---- the second labelling on the region graph (post_engine.hip: postprocess, N > 1)
+// region_stats + box[id][6] = {zmin, ymin, xmin, zmax, ymax, xmax} of every region with id <= cap (box: 6 * (cap + 1) ints, preset here)
+hipError_t region_stats_box(const int* ids, const uint8_t* lab, int* area, uint8_t* labval, int* box, Dims d, hipStream_t s, int cap);
+// (smaller id << 32 | larger id) of regions with voxels that touch diagonally (26- but not 6-adjacent); duplicates possible;
+// *count_dev is raised for every pair, stored or not (cap)
+hipError_t diag_pairs(const uint8_t* lab, const int* ids, Dims d, unsigned long long* pairs, unsigned* count_dev, unsigned cap, hipStream_t s);
 
 // ---- per-label largest component + hole filling
 // area_by_root[root] = component size (array of nvox ints, zeroed here); best[256] u64 = max over the
@@ -68,6 +77,10 @@ hipError_t complement_of_component_box(const int* parent, int keep_root, Dims d,
 // box-local labelling bgparent/flags
 hipError_t fill_write_box(const int* parent, int keep_root, const int* bgparent, const int* flags, uint8_t label, uint8_t* out, Dims d, Box box,
                           hipStream_t s);
+// complement_of_component_box / fill_write_box with "in the kept component of `label`" == keeplut[ids[v]] == label
+hipError_t complement_of_lut_box(const int* ids, const uint8_t* keeplut, uint8_t label, Dims d, Box box, uint8_t* bg, hipStream_t s);
+hipError_t fill_write_lut_box(const int* ids, const uint8_t* keeplut, const int* bgparent, const int* flags, uint8_t label, uint8_t* out, Dims d, Box box,
+                              hipStream_t s);
 
 // ---- slab-sharded post-processing (slab_engine.hip): the same passes on ONE rank's slices, plus the few
 //      planes/tables that tie the slabs together.  "atom" = component of the slab-local labelling (dense id).

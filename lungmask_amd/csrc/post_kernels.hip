@@ -343,6 +343,15 @@ __global__ __launch_bounds__(TPB) void assign_rank_kernel(const int* __restrict_
     }
 }
 
+// the same on a forest that was not flattened: the (short, path-halved) chain to the root is walked here, which spares the
+// labelling its own read-modify-write pass over the parent volume when nothing else needs flat parents
+__global__ __launch_bounds__(TPB) void relabel_find_kernel(const int* __restrict__ P, const int* __restrict__ rank, int* __restrict__ ids, size_t nvox) {
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x) {
+        const int r = P[v];
+        ids[v] = r >= 0 ? rank[find_root(P, r)] : 0;
+    }
+}
+
 __global__ __launch_bounds__(TPB) void relabel_kernel(const int* __restrict__ P, const int* __restrict__ rank, int* __restrict__ ids, size_t nvox) {
     for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x) {
         const int r = P[v];
@@ -759,9 +768,288 @@ __global__ __launch_bounds__(TPB) void fuse_kernel(uint8_t* res_l, const uint8_t
     }
 }
 
+// ---- the second labelling on the region graph (post_engine.hip: postprocess) -------------------------------------------------
+// After the merge loop every voxel's mapped label is lut[region]; the components of the mapped volume are therefore unions of
+// first-pass regions, and which regions belong together follows from the region ADJACENCY: the 6-adjacency is in the boundary
+// records already, the rest of the 26-adjacency (pairs of regions that only touch diagonally) comes from diag_pairs_kernel, the
+// regions' areas and bounding boxes from region_stats_box_kernel.  The host then finds the largest component of every label on a
+// graph of ~10^3 nodes, and no second voxel-level labelling / area / bounding-box pass runs at all.
+
+// region_stats_kernel + the bounding box of every region: box[id][6] = {zmin, ymin, xmin, zmax, ymax, xmax} (preset by the
+// caller: mins INT_MAX, maxs -1).  Runs of equal ids inside a 64-voxel segment (broken at row starts) go through a per-workgroup
+// LDS table -- a large region costs one set of global atomics per workgroup, not per run -- and a global atomic is only issued
+// when the (possibly stale, but monotone) value in memory does not already cover the workgroup's.
+__global__ __launch_bounds__(TPB) void region_stats_box_kernel(const int* __restrict__ ids, const uint8_t* __restrict__ lab, int* area, uint8_t* labval,
+                                                               int* box, Dims d, int cap) {
+    __shared__ int hkey[HS];
+    __shared__ int hcnt[HS];
+    __shared__ int hb[6][HS];
+    for (int i = threadIdx.x; i < HS; i += blockDim.x) {
+        hkey[i] = H_EMPTY;
+        hcnt[i] = 0;
+        hb[0][i] = hb[1][i] = hb[2][i] = 0x7fffffff;
+        hb[3][i] = hb[4][i] = hb[5][i] = -1;
+    }
+    __syncthreads();
+    const size_t nvox = d.nvox();
+    const size_t nseg = (nvox + 63) / 64;
+    const size_t per = (nseg + gridDim.x - 1) / gridDim.x;
+    const size_t seg0 = (size_t)blockIdx.x * per;
+    const size_t seg1 = seg0 + per < nseg ? seg0 + per : nseg;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    auto gmin = [](int* p, int v) { if (v < *(volatile int*)p) atomicMin(p, v); };
+    auto gmax = [](int* p, int v) { if (v > *(volatile int*)p) atomicMax(p, v); };
+    for (size_t seg = seg0 + wave; seg < seg1; seg += nw) {
+        const size_t v = seg * 64 + lane;
+        int id = v < nvox ? ids[v] : 0;
+        if (id > cap) id = 0;
+        const unsigned q = (unsigned)v / (unsigned)d.W;
+        const int x = (int)((unsigned)v - q * (unsigned)d.W);
+        const int prev = __shfl_up(id, 1);
+        const bool head = lane == 0 || prev != id || x == 0;
+        const unsigned long long heads = __ballot(head);
+        if (head && id) {
+            const unsigned long long higher = lane == 63 ? 0ull : (heads >> (lane + 1));
+            const int len = higher ? __ffsll((long long)higher) : 64 - lane;
+            const int z = (int)(q / (unsigned)d.H), y = (int)(q - (unsigned)z * (unsigned)d.H);
+            labval[id] = lab[v];
+            unsigned h = ((unsigned)id * 2654435761u) >> 22;
+            int slot = -1;
+            for (int probe = 0; probe < 8; ++probe) {
+                const int old = atomicCAS(&hkey[h], H_EMPTY, id);
+                if (old == H_EMPTY || old == id) {
+                    slot = (int)h;
+                    break;
+                }
+                h = (h + 1) & (HS - 1);
+            }
+            if (slot >= 0) {
+                atomicAdd(&hcnt[slot], len);
+                if (z < hb[0][slot]) atomicMin(&hb[0][slot], z);
+                if (y < hb[1][slot]) atomicMin(&hb[1][slot], y);
+                if (x < hb[2][slot]) atomicMin(&hb[2][slot], x);
+                if (z > hb[3][slot]) atomicMax(&hb[3][slot], z);
+                if (y > hb[4][slot]) atomicMax(&hb[4][slot], y);
+                if (x + len - 1 > hb[5][slot]) atomicMax(&hb[5][slot], x + len - 1);
+            } else {  // table full around this slot: straight to memory
+                atomicAdd(&area[id], len);
+                int* b = box + 6 * (size_t)id;
+                gmin(b + 0, z); gmin(b + 1, y); gmin(b + 2, x);
+                gmax(b + 3, z); gmax(b + 4, y); gmax(b + 5, x + len - 1);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HS; i += blockDim.x) {
+        if (hkey[i] == H_EMPTY || !hcnt[i]) continue;
+        atomicAdd(&area[hkey[i]], hcnt[i]);
+        int* b = box + 6 * (size_t)hkey[i];
+        gmin(b + 0, hb[0][i]); gmin(b + 1, hb[1][i]); gmin(b + 2, hb[2][i]);
+        gmax(b + 3, hb[3][i]); gmax(b + 4, hb[4][i]); gmax(b + 5, hb[5][i]);
+    }
+}
+
+__global__ __launch_bounds__(TPB) void region_box_init_kernel(int* box, size_t n_regions) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < 6 * n_regions; i += (size_t)gridDim.x * blockDim.x) box[i] = (i % 6) < 3 ? 0x7fffffff : -1;
+}
+
+// Pairs of regions that touch DIAGONALLY (26- but not 6-adjacent voxels with two different non-zero labels: two voxels of one
+// label that touch belong to one region).  Each pair of voxels is seen from its raster-later member; pairs are deduplicated per
+// workgroup in an LDS table (a key that finds its 8 probe slots taken goes out on its own) and appended to `pairs` as
+// (smaller id << 32 | larger id); duplicates across workgroups are harmless (the host unites).  Voxel-wise: any row length.
+constexpr int PHS = 1024;
+__device__ __forceinline__ void pair_emit(unsigned long long* hk, int a, int b, unsigned long long* pairs, unsigned* count, unsigned cap) {
+    if (a == b || a == 0 || b == 0) return;
+    const unsigned long long key = a < b ? ((unsigned long long)(unsigned)a << 32) | (unsigned)b : ((unsigned long long)(unsigned)b << 32) | (unsigned)a;
+    unsigned h = (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 54);  // 10 bits
+    for (int probe = 0; probe < 8; ++probe) {
+        const unsigned long long old = atomicCAS(&hk[h], 0ull, key);
+        if (old == 0ull || old == key) return;
+        h = (h + 1) & (PHS - 1);
+    }
+    const unsigned o = atomicAdd(count, 1u);
+    if (o < cap) pairs[o] = key;
+}
+
+__global__ __launch_bounds__(TPB) void diag_pairs_kernel(const uint8_t* __restrict__ lab, const int* __restrict__ ids, Dims d, unsigned long long* pairs,
+                                                         unsigned* count, unsigned cap, size_t per_block) {
+    __shared__ unsigned long long hk[PHS];
+    for (int i = threadIdx.x; i < PHS; i += blockDim.x) hk[i] = 0ull;
+    __syncthreads();
+    const size_t nvox = d.nvox();
+    const int W = d.W, HW = d.H * d.W;
+    const size_t v0 = (size_t)blockIdx.x * per_block;
+    const size_t v1 = v0 + per_block < nvox ? v0 + per_block : nvox;
+    for (size_t v = v0 + threadIdx.x; v < v1; v += blockDim.x) {
+        const unsigned L = lab[v];
+        if (!L) continue;
+        int x, y, z;
+        split3(v, d.H, d.W, x, y, z);
+        // the ten raster-earlier neighbours that are not 6-neighbours: (x +- 1, y - 1, z) and, in slice z - 1, all of the 3 x 3
+        // block around (x, y) except its centre
+        int mine = 0;
+        auto look = [&](long long u) {
+            const unsigned Lu = lab[u];
+            if (Lu && Lu != L) {
+                if (!mine) mine = ids[v];
+                pair_emit(hk, mine, ids[u], pairs, count, cap);
+            }
+        };
+        if (y > 0) {
+            if (x > 0) look((long long)v - W - 1);
+            if (x + 1 < W) look((long long)v - W + 1);
+        }
+        if (z > 0) {
+            for (int dy = -1; dy <= 1; ++dy) {
+                if (y + dy < 0 || y + dy >= d.H) continue;
+                for (int dx = -1; dx <= 1; ++dx) {
+                    if ((dy == 0 && dx == 0) || x + dx < 0 || x + dx >= W) continue;
+                    look((long long)v - HW + dy * W + dx);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PHS; i += blockDim.x) {
+        if (!hk[i]) continue;
+        const unsigned o = atomicAdd(count, 1u);
+        if (o < cap) pairs[o] = hk[i];
+    }
+}
+
+// The same for rows that are a multiple of 4 long (every volume of the hot path), in the style of ccl_merge_rows_kernel: one wave per
+// 256-voxel piece of a row, four voxels per lane from one 32-bit load per row involved, neighbour bytes from the neighbour lanes;
+// the label words decide, region ids are only loaded where two different labels meet.
+__global__ __launch_bounds__(TPB) void diag_pairs_rows_kernel(const uint8_t* __restrict__ lab, const int* __restrict__ ids, Dims d, unsigned long long* pairs,
+                                                              unsigned* count, unsigned cap, unsigned pieces_per_block) {
+    __shared__ unsigned long long hk[PHS];
+    for (int i = threadIdx.x; i < PHS; i += blockDim.x) hk[i] = 0ull;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned ppr = ((unsigned)d.W + 255u) >> 8;
+    const unsigned npieces = (unsigned)d.N * (unsigned)d.H * ppr;
+    const int W = d.W, HW = d.H * d.W;
+    const unsigned p0 = blockIdx.x * pieces_per_block, p1 = min(npieces, p0 + pieces_per_block);
+    for (unsigned piece = p0 + wave; piece < p1; piece += TPB / 64) {
+        const unsigned row = piece / ppr;
+        const int z = (int)(row / (unsigned)d.H), y = (int)(row - (unsigned)z * (unsigned)d.H);
+        const int x = (int)((piece - row * ppr) << 8) + lane * 4;
+        const bool in = x < W;
+        const int v = (int)row * W + x;
+        const unsigned w = in ? *reinterpret_cast<const unsigned*>(lab + v) : 0u;
+        if (__ballot(w != 0) == 0 || (y == 0 && z == 0)) continue;
+        // a row's word for this lane plus the voxels left and right of it (bytes 0 and 5); off: wave-uniform, a multiple of 4
+        auto load_row = [&](int off) {
+            const int u = v + off;
+            const unsigned uw = in ? *reinterpret_cast<const unsigned*>(lab + u) : 0u;
+            unsigned ul = __shfl_up(uw, 1) >> 24, ur = __shfl_down(uw, 1) & 0xffu;
+            if (lane == 0) ul = x > 0 ? lab[u - 1] : 0u;
+            if (lane == 63) ur = (in && x + 4 < W) ? lab[u + 4] : 0u;
+            return ((unsigned long long)ur << 40) | ((unsigned long long)uw << 8) | ul;
+        };
+        // voxel j of this lane against the row at `off`: the left / right neighbour there, and (centre) the one straight across
+        auto scan_row = [&](int off, unsigned long long theirs, bool centre) {
+            if (w == 0) return;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned L = (w >> (8 * j)) & 0xffu;
+                if (!L) continue;
+                const unsigned ul = (unsigned)(theirs >> (8 * j)) & 0xffu, uc = (unsigned)(theirs >> (8 * j + 8)) & 0xffu, ur = (unsigned)(theirs >> (8 * j + 16)) & 0xffu;
+                const bool hl = ul && ul != L, hc = centre && uc && uc != L, hr = ur && ur != L;
+                if (!(hl || hc || hr)) continue;
+                const int a = ids[v + j];
+                if (hl) pair_emit(hk, a, ids[v + off + j - 1], pairs, count, cap);
+                if (hc) pair_emit(hk, a, ids[v + off + j], pairs, count, cap);
+                if (hr) pair_emit(hk, a, ids[v + off + j + 1], pairs, count, cap);
+            }
+        };
+        unsigned long long ra = 0, rb = 0, rab = 0, rbb = 0;  // above (y-1, z), behind (y, z-1), above-behind, below-behind
+        if (y > 0) ra = load_row(-W);
+        if (z > 0) {
+            rb = load_row(-HW);
+            if (y > 0) rab = load_row(-HW - W);
+            if (y + 1 < d.H) rbb = load_row(-HW + W);
+        }
+        if (y > 0) scan_row(-W, ra, false);
+        if (z > 0) {
+            scan_row(-HW, rb, false);
+            if (y > 0) scan_row(-HW - W, rab, true);
+            if (y + 1 < d.H) scan_row(-HW + W, rbb, true);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PHS; i += blockDim.x) {
+        if (!hk[i]) continue;
+        const unsigned o = atomicAdd(count, 1u);
+        if (o < cap) pairs[o] = hk[i];
+    }
+}
+
+// box kernels of the hole fill driven by the region table instead of a second labelling: "in the kept component of `label`" ==
+// keeplut[ids[v]] == label
+__global__ __launch_bounds__(TPB) void complement_lut_box_kernel(const int* __restrict__ ids, const uint8_t* __restrict__ keeplut, uint8_t label, Dims d, Box box,
+                                                                 uint8_t* __restrict__ bg) {
+    const size_t n = box.d.nvox();
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (size_t)gridDim.x * blockDim.x) {
+        int x, y, z;
+        split3(c, box.d.H, box.d.W, x, y, z);
+        const size_t v = ((size_t)(box.z0 + z) * d.H + (box.y0 + y)) * d.W + (box.x0 + x);
+        bg[c] = keeplut[ids[v]] != label ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void fill_write_lut_box_kernel(const int* __restrict__ ids, const uint8_t* __restrict__ keeplut, const int* __restrict__ BP,
+                                                                 const int* __restrict__ flags, uint8_t label, uint8_t* out, Dims d, Box box) {
+    const size_t n = box.d.nvox();
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (size_t)gridDim.x * blockDim.x) {
+        int x, y, z;
+        split3(c, box.d.H, box.d.W, x, y, z);
+        const size_t v = ((size_t)(box.z0 + z) * d.H + (box.y0 + y)) * d.W + (box.x0 + x);
+        bool on = keeplut[ids[v]] == label;
+        if (!on) {
+            const int r = BP[c];
+            on = r >= 0 && flags[r] == 0;
+        }
+        if (on) out[v] = label;
+    }
+}
+
 }  // namespace
 
-hipError_t ccl_label(const uint8_t* lab, int* parent, Dims d, bool conn26, hipStream_t s) {
+hipError_t region_stats_box(const int* ids, const uint8_t* lab, int* area, uint8_t* labval, int* box, Dims d, hipStream_t s, int cap) {
+    LM_LAUNCH(region_box_init_kernel, dim3(grid_for((size_t)6 * ((size_t)cap + 1))), dim3(TPB), 0, s, box, (size_t)cap + 1);
+    LM_LAUNCH(region_stats_box_kernel, dim3(grid_for(d.nvox(), 64 * 64, 2048)), dim3(TPB), 0, s, ids, lab, area, labval, box, d, cap);
+    return hipGetLastError();
+}
+
+hipError_t diag_pairs(const uint8_t* lab, const int* ids, Dims d, unsigned long long* pairs, unsigned* count_dev, unsigned cap, hipStream_t s) {
+    const size_t nvox = d.nvox();
+    if (nvox == 0) return hipSuccess;
+    if (d.W % 4 == 0 && (reinterpret_cast<uintptr_t>(lab) & 3) == 0 && nvox < (size_t)0x7fffffff) {
+        const size_t pieces = (size_t)d.N * d.H * ((d.W + 255) / 256);
+        // contiguous ranges of pieces per workgroup (the longer the range, the more voxels share a table), >= 2048 workgroups when the volume has them
+        const unsigned ppb = (unsigned)std::max<size_t>((pieces + 2047) / 2048, 16);
+        LM_LAUNCH(diag_pairs_rows_kernel, dim3((unsigned)((pieces + ppb - 1) / ppb)), dim3(TPB), 0, s, lab, ids, d, pairs, count_dev, cap, ppb);
+    } else {
+        size_t per = (nvox + 2047) / 2048;
+        per = std::max<size_t>((per + TPB - 1) / TPB * TPB, 8 * TPB);
+        LM_LAUNCH(diag_pairs_kernel, dim3((unsigned)((nvox + per - 1) / per)), dim3(TPB), 0, s, lab, ids, d, pairs, count_dev, cap, per);
+    }
+    return hipGetLastError();
+}
+
+hipError_t complement_of_lut_box(const int* ids, const uint8_t* keeplut, uint8_t label, Dims d, Box box, uint8_t* bg, hipStream_t s) {
+    LM_LAUNCH(complement_lut_box_kernel, dim3(grid_for(box.d.nvox())), dim3(TPB), 0, s, ids, keeplut, label, d, box, bg);
+    return hipGetLastError();
+}
+
+hipError_t fill_write_lut_box(const int* ids, const uint8_t* keeplut, const int* bgparent, const int* flags, uint8_t label, uint8_t* out, Dims d, Box box,
+                              hipStream_t s) {
+    LM_LAUNCH(fill_write_lut_box_kernel, dim3(grid_for(box.d.nvox())), dim3(TPB), 0, s, ids, keeplut, bgparent, flags, label, out, d, box);
+    return hipGetLastError();
+}
+
+hipError_t ccl_label(const uint8_t* lab, int* parent, Dims d, bool conn26, hipStream_t s, bool flatten) {
     const size_t n = d.nvox();
     if (n == 0) return hipSuccess;
     if (d.W % 4 == 0 && (reinterpret_cast<uintptr_t>(lab) & 3) == 0 && (reinterpret_cast<uintptr_t>(parent) & 15) == 0 && n < (size_t)0x7fffffff) {
@@ -779,19 +1067,20 @@ hipError_t ccl_label(const uint8_t* lab, int* parent, Dims d, bool conn26, hipSt
         else
             LM_LAUNCH((ccl_merge_kernel<false>), dim3(grid_for(n)), dim3(TPB), 0, s, lab, parent, d);
     }
-    LM_LAUNCH(ccl_flatten_kernel, dim3(grid_for(n)), dim3(TPB), 0, s, parent, n);
+    if (flatten) LM_LAUNCH(ccl_flatten_kernel, dim3(grid_for(n)), dim3(TPB), 0, s, parent, n);
     return hipGetLastError();
 }
 
 size_t rank_blocks(size_t nvox) { return (nvox + BLOCK_VOX - 1) / BLOCK_VOX; }
 
-hipError_t ccl_rank(const int* parent, int* rank, int* ids, int* blockcnt, int* total_dev, size_t nvox, hipStream_t s) {
+hipError_t ccl_rank(const int* parent, int* rank, int* ids, int* blockcnt, int* total_dev, size_t nvox, hipStream_t s, bool flat) {
     const size_t nb = rank_blocks(nvox);
     if (nb == 0) return hipSuccess;
     LM_LAUNCH(count_roots_kernel, dim3((unsigned)nb), dim3(TPB), 0, s, parent, blockcnt, nvox);
     LM_LAUNCH(scan_blockcnt_kernel, dim3(1), dim3(1024), 0, s, blockcnt, (int)nb, total_dev);
     LM_LAUNCH(assign_rank_kernel, dim3((unsigned)nb), dim3(TPB), 0, s, parent, rank, (const int*)blockcnt, nvox);
-    LM_LAUNCH(relabel_kernel, dim3(grid_for(nvox)), dim3(TPB), 0, s, parent, (const int*)rank, ids, nvox);
+    if (flat) LM_LAUNCH(relabel_kernel, dim3(grid_for(nvox)), dim3(TPB), 0, s, parent, (const int*)rank, ids, nvox);
+    else LM_LAUNCH(relabel_find_kernel, dim3(grid_for(nvox)), dim3(TPB), 0, s, parent, (const int*)rank, ids, nvox);
     return hipGetLastError();
 }
 

@@ -258,3 +258,35 @@ def check_apply_host_failure_leaves_output_untouched(eng):
         raise AssertionError("an empty model slot must be an error")
     assert (out == 0xAB).all()
     eng.sync()
+
+
+def check_postprocess_diagonal_adversarial(eng, n_iter=60):
+    """The second labelling runs on the region graph (csrc/post_engine.hip: graph_components): components of the mapped volume are
+    unions of first-pass regions joined by 6-adjacency (boundary records) and by the diagonal rest of the 26-adjacency
+    (diag_pairs kernels, row-wise and voxel-wise).  Volumes made to stress exactly that -- pure label noise, blobs with noise,
+    volumes without a background voxel, diagonal chains -- against the oracle, with and without a spare label, widths that are
+    and are not multiples of 4."""
+    from oracle.make_golden import random_blobs
+
+    rng = np.random.default_rng(123)
+    shapes = [(5, 12, 12), (4, 10, 14), (6, 9, 11), (3, 16, 8), (2, 7, 9)]
+    for it in range(n_iter):
+        shape = shapes[it % 5]
+        kind = it % 4
+        if kind == 0:
+            lab = rng.integers(0, 4, shape).astype(np.uint8)
+        elif kind == 1:
+            lab = random_blobs(rng, shape, 3, 6, 0.4)
+            lab[rng.random(shape) < 0.15] = rng.integers(1, 4)
+        elif kind == 2:
+            lab = rng.integers(1, 4, shape).astype(np.uint8)
+        else:
+            lab = np.zeros(shape, np.uint8)
+            zz, yy, xx = np.indices(shape)
+            m = (zz + yy + xx) % 2 == 0
+            lab[m] = (1 + ((zz + 2 * yy + 3 * xx) % 3 == 0))[m]
+            lab[rng.random(shape) < 0.1] = 3
+        for spare, skip in (((), 3), ((3,), 3), ((), 1)):
+            out = eng.postprocess(lab, spare=list(spare), skip_below=skip)
+            ref = po.postprocessing(lab.copy(), spare=list(spare), skip_below=skip)
+            assert np.array_equal(out, ref), (it, shape, kind, spare, skip, int((out != ref).sum()))

@@ -31,6 +31,10 @@ def test_postprocessing_random_differential(gpu_engine):
     cases.check_postprocess_random(gpu_engine, seeds=range(100, 104), shape=(24, 96, 80), nlab=5)
 
 
+def test_postprocessing_diagonal_adversarial(gpu_engine):
+    cases.check_postprocess_diagonal_adversarial(gpu_engine, n_iter=160)
+
+
 def test_postprocessing_wide_rows(gpu_engine):
     cases.check_postprocess_wide_rows(gpu_engine)
 

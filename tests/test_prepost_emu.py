@@ -23,6 +23,10 @@ def test_postprocessing_emulated_random_differential(emu_engine):
     cases.check_postprocess_random(emu_engine, seeds=range(4))
 
 
+def test_postprocessing_emulated_diagonal_adversarial(emu_engine):
+    cases.check_postprocess_diagonal_adversarial(emu_engine)
+
+
 def test_postprocessing_emulated_wide_rows(emu_engine):
     cases.check_postprocess_wide_rows(emu_engine)
 
