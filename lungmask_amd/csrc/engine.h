@@ -135,10 +135,13 @@ struct PostWorkspace {
     unsigned last_records = 0, last_pairs = 0;
     DevBuf parent, ids, rank, bgparent, blockcnt, area, labval, recs, lut, mapped, bg, out, scalars, bbox;
     DevBuf rbox, pairs;  // region-graph form of the second labelling: bounding box per region, diagonal adjacency pairs
+    hipEvent_t tables_ready = nullptr;  // behind the first read-back (the host replays the merge while the boxes / pairs kernels run)
     void release() {
         parent.release(); ids.release(); rank.release(); bgparent.release(); blockcnt.release(); area.release(); labval.release();
         recs.release(); lut.release(); mapped.release(); bg.release(); out.release(); scalars.release(); bbox.release();
         rbox.release(); pairs.release();
+        if (tables_ready) (void)hipEventDestroy(tables_ready);
+        tables_ready = nullptr;
         h_area.release(); h_labval.release(); h_recs.release(); h_scalars.release(); h_rbox.release(); h_pairs.release();
     }
 };

@@ -48,13 +48,18 @@ struct ProfScope {
 // utils.py:303-342 on the region graph.  Returns lut[atom] = final label value (0 = removed).
 void replay_merge(int R, const int* area, const uint8_t* lv, const BoundaryRec* recs, size_t nrecs, const std::vector<int>& spare,
                   int skip_below, std::vector<uint8_t>& lut, PostInfo& info) {
-    std::vector<int> order(R);
+    // (the tables of this function and of graph_components live across calls: a dozen allocations of ~100 KB each per volume were
+    // a measurable part of the 0.2 ms the replay takes)
+    static thread_local std::vector<int> order;
+    order.resize(R);
     std::iota(order.begin(), order.end(), 1);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return area[a] < area[b]; });  // :299
     unsigned maxsub[256];
     memset(maxsub, 0, sizeof maxsub);
-    std::vector<uint8_t> lobemap(R + 1, 0);
-    std::vector<long long> cache_area(area, area + R + 1);
+    static thread_local std::vector<uint8_t> lobemap;
+    static thread_local std::vector<long long> cache_area;
+    lobemap.assign(R + 1, 0);
+    cache_area.assign(area, area + R + 1);
     for (int r : order) {  // :303-308
         const int mi = lv[r];
         if (cache_area[r] > (long long)maxsub[mi]) {
@@ -72,18 +77,21 @@ void replay_merge(int R, const int* area, const uint8_t* lv, const BoundaryRec* 
         return false;
     };
     // adjacency: atom -> records in which it appears as a neighbour
-    std::vector<unsigned> adj_off(R + 2, 0);
+    static thread_local std::vector<unsigned> adj_off, adj, fill;
+    adj_off.assign(R + 2, 0);
     for (size_t j = 0; j < nrecs; ++j)
         for (int k = 0; k < 6 && recs[j].nb[k]; ++k) adj_off[recs[j].nb[k] + 1]++;
     for (int i = 1; i <= R + 1; ++i) adj_off[i] += adj_off[i - 1];
-    std::vector<unsigned> adj(adj_off[R + 1]);
+    adj.resize(adj_off[R + 1]);
     {
-        std::vector<unsigned> fill(adj_off.begin(), adj_off.end() - 1);
+        fill.assign(adj_off.begin(), adj_off.end() - 1);
         for (size_t j = 0; j < nrecs; ++j)
             for (int k = 0; k < 6 && recs[j].nb[k]; ++k) adj[fill[recs[j].nb[k]]++] = (unsigned)j;
     }
     // current id of every atom: union-find + member lists
-    std::vector<int> uf(R + 1), setid(R + 1), head(R + 1), tail(R + 1), next(R + 1, 0), rep(R + 1);
+    static thread_local std::vector<int> uf, setid, head, tail, next, rep;
+    uf.resize(R + 1), setid.resize(R + 1), head.resize(R + 1), tail.resize(R + 1), rep.resize(R + 1);
+    next.assign(R + 1, 0);
     for (int i = 0; i <= R; ++i) uf[i] = setid[i] = head[i] = tail[i] = rep[i] = i;
     auto find = [&](int a) {
         while (uf[a] != a) {
@@ -92,7 +100,10 @@ void replay_merge(int R, const int* area, const uint8_t* lv, const BoundaryRec* 
         }
         return a;
     };
-    std::vector<int> stamp(nrecs, 0), counts(R + 1, 0), touched;
+    static thread_local std::vector<int> stamp, counts, touched;
+    stamp.assign(nrecs, 0);
+    counts.assign(R + 1, 0);
+    touched.clear();
     for (int r : order) {  // :310-339
         const int mi = lv[r];
         if (!((cache_area[r] < (long long)maxsub[mi] || spare_label[mi]) && cache_area[r] >= skip_below)) continue;
@@ -148,7 +159,9 @@ void replay_merge(int R, const int* area, const uint8_t* lv, const BoundaryRec* 
 // keeplut[region] = its label when the region belongs to its label's kept component, else 0; lbox[label] = that component's box.
 static void graph_components(int R, const int* area, const std::vector<uint8_t>& lut, const BoundaryRec* recs, size_t nrecs, const unsigned long long* pairs,
                              size_t npairs, const int* rbox, int dropped_label, std::vector<uint8_t>& keeplut, int lbox[256][6], bool kept[256]) {
-    std::vector<int> uf(R + 1);
+    static thread_local std::vector<int> uf;
+    static thread_local std::vector<long long> carea;
+    uf.resize(R + 1);
     std::iota(uf.begin(), uf.end(), 0);
     auto find = [&](int a) {
         while (uf[a] != a) {
@@ -168,7 +181,7 @@ static void graph_components(int R, const int* area, const std::vector<uint8_t>&
     for (size_t j = 0; j < nrecs; ++j)
         for (int k = 0; k < 6 && recs[j].nb[k]; ++k) unite(recs[j].atom, recs[j].nb[k]);
     for (size_t j = 0; j < npairs; ++j) unite((int)(pairs[j] >> 32), (int)(pairs[j] & 0xffffffffull));
-    std::vector<long long> carea(R + 1, 0);
+    carea.assign(R + 1, 0);
     for (int a = 1; a <= R; ++a)
         if (lut[a]) carea[find(a)] += area[a];
     int best[256];
@@ -264,6 +277,7 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
     unsigned pcap = tiny ? 8u : (unsigned)std::max<size_t>(ws.pairs.cap / 8, 1u << 18);
     int R = 0;
     unsigned nrec = 0, npair = 0;
+    size_t g_p = 0, g_r_used = 0;  // what the speculative read-backs of the pairs / the boxes fetched
     std::vector<uint8_t> lut(1, 0);
     const int* area = nullptr;
     const uint8_t* lv = nullptr;
@@ -276,12 +290,7 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
         // ---- (2) regionprops: area + label value                                           utils.py:298
         LM_HIP(hipMemsetAsync(ws.area.p, 0, ((size_t)rcap + 1) * 4, s));
         LM_HIP(hipMemsetAsync(ws.labval.p, 0, (size_t)rcap + 1, s));
-        if (graph) {
-            LM_TRY(ws.rbox.reserve(((size_t)rcap + 1) * 6 * 4));
-            LM_TRY(ws.pairs.reserve((size_t)pcap * 8));
-            ProfScope ps(e, "post_region_stats", (double)nvox * 5);
-            LM_K(region_stats_box(ids, lab, ws.area.as<int>(), ws.labval.as<uint8_t>(), ws.rbox.as<int>(), d, s, rcap));
-        } else {
+        {
             ProfScope ps(e, "post_region_stats", (double)nvox * 5);
             LM_K(region_stats(ids, lab, ws.area.as<int>(), ws.labval.as<uint8_t>(), nvox, s, rcap));
         }
@@ -291,31 +300,44 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
             ProfScope ps(e, "post_boundary_records", (double)nvox * 4);
             LM_K(boundary_records(ids, d, ws.recs.as<BoundaryRec>(), count_dev, cap, s));
         }
-        if (graph) {  // regions that touch only diagonally (the rest of the 26-adjacency)
-            LM_HIP(hipMemsetAsync(pcount_dev, 0, sizeof(unsigned), s));
-            ProfScope ps(e, "post_diag_pairs", (double)nvox * 2);
-            LM_K(diag_pairs(lab, ids, d, ws.pairs.as<unsigned long long>(), pcount_dev, pcap, s));
-        }
         // speculative read-back
         const size_t g_r = tiny ? (size_t)std::min(rcap, 4) : (size_t)std::min(rcap, std::max(4096, ws.last_regions + ws.last_regions / 4 + 256));
         const size_t g_n = tiny ? std::min<size_t>(cap, 4) : std::min<size_t>(cap, std::max<size_t>(32768, (size_t)ws.last_records + ws.last_records / 4 + 1024));
         LM_TRY(ws.h_area.reserve((g_r + 1) * 4));
         LM_TRY(ws.h_labval.reserve(g_r + 1));
         LM_TRY(ws.h_recs.reserve(g_n * sizeof(BoundaryRec)));
-        const size_t g_p = tiny ? std::min<size_t>(pcap, 4) : std::min<size_t>(pcap, std::max<size_t>(16384, (size_t)ws.last_pairs + ws.last_pairs / 4 + 1024));
-        if (graph) {
-            LM_TRY(ws.h_rbox.reserve((g_r + 1) * 6 * 4));
-            LM_TRY(ws.h_pairs.reserve(g_p * 8));
-            LM_HIP(hipMemcpyAsync(ws.h_rbox.p, ws.rbox.p, (g_r + 1) * 6 * 4, hipMemcpyDeviceToHost, s));
-            LM_HIP(hipMemcpyAsync(ws.h_pairs.p, ws.pairs.p, g_p * 8, hipMemcpyDeviceToHost, s));
-        }
-        LM_HIP(hipMemcpyAsync(ws.h_scalars.p, total_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, s));  // total_dev, count_dev, (fusion's max), pcount_dev
+        LM_HIP(hipMemcpyAsync(ws.h_scalars.p, total_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, s));  // total_dev, count_dev are neighbours
         if (want_range && attempt == 0) LM_HIP(hipMemcpyAsync(e->range_flag_host, e->range_flag, sizeof(unsigned), hipMemcpyDeviceToHost, s));
         LM_HIP(hipMemcpyAsync(ws.h_area.p, ws.area.p, (g_r + 1) * 4, hipMemcpyDeviceToHost, s));
         LM_HIP(hipMemcpyAsync(ws.h_labval.p, ws.labval.p, g_r + 1, hipMemcpyDeviceToHost, s));
         LM_HIP(hipMemcpyAsync(ws.h_recs.p, ws.recs.p, g_n * sizeof(BoundaryRec), hipMemcpyDeviceToHost, s));
+        if (graph) {
+            // The region-graph inputs of step 5 -- every region's bounding box and the pairs of regions that only touch diagonally --
+            // are not needed by the merge replay: their kernels and their read-back are enqueued BEHIND the first read-back, the host
+            // waits for an event between the two and replays the merge while they run.
+            if (!ws.tables_ready) LM_HIP(hipEventCreateWithFlags(&ws.tables_ready, hipEventDisableTiming));
+            LM_HIP(hipEventRecord(ws.tables_ready, s));
+            LM_TRY(ws.rbox.reserve(((size_t)rcap + 1) * 6 * 4));
+            LM_TRY(ws.pairs.reserve((size_t)pcap * 8));
+            {
+                ProfScope ps(e, "post_region_boxes", (double)nvox * 4);
+                LM_K(region_stats_box(ids, lab, nullptr, nullptr, ws.rbox.as<int>(), d, s, rcap));
+            }
+            LM_HIP(hipMemsetAsync(pcount_dev, 0, sizeof(unsigned), s));
+            {
+                ProfScope ps(e, "post_diag_pairs", (double)nvox * 2);
+                LM_K(diag_pairs(lab, ids, d, ws.pairs.as<unsigned long long>(), pcount_dev, pcap, s));
+            }
+            g_p = tiny ? std::min<size_t>(pcap, 4) : std::min<size_t>(pcap, std::max<size_t>(16384, (size_t)ws.last_pairs + ws.last_pairs / 4 + 1024));
+            LM_TRY(ws.h_rbox.reserve((g_r + 1) * 6 * 4));
+            LM_TRY(ws.h_pairs.reserve(g_p * 8));
+            LM_HIP(hipMemcpyAsync(const_cast<int*>(hs) + 3, pcount_dev, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+            LM_HIP(hipMemcpyAsync(ws.h_rbox.p, ws.rbox.p, (g_r + 1) * 6 * 4, hipMemcpyDeviceToHost, s));
+            LM_HIP(hipMemcpyAsync(ws.h_pairs.p, ws.pairs.p, g_p * 8, hipMemcpyDeviceToHost, s));
+        }
         t_enq1 = ms_now();
-        LM_HIP(hipStreamSynchronize(s));
+        if (graph) LM_HIP(hipEventSynchronize(ws.tables_ready));
+        else LM_HIP(hipStreamSynchronize(s));
         t_sync1 = ms_now();
         if (want_range && attempt == 0) {
             LM_TRY(range_flag_consume(e, range_slot, range_tripped));
@@ -323,19 +345,11 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
         }
         R = hs[0];
         nrec = (unsigned)hs[1];
-        npair = graph ? (unsigned)hs[3] : 0u;
-        if (R > rcap || nrec > cap || npair > pcap) {  // rare: a table was too small -- grow and repeat the passes
+        if (R > rcap || nrec > cap) {  // rare: a table was too small -- grow and repeat the passes
             rcap = std::max(rcap, R);
             cap = std::max(cap, nrec);
-            pcap = std::max(pcap, npair);
+            if (graph) LM_HIP(hipStreamSynchronize(s));  // (the boxes / pairs kernels of this attempt write tables that are about to grow)
             continue;
-        }
-        if (graph && ((size_t)R > g_r || npair > g_p)) {
-            LM_TRY(ws.h_rbox.reserve(((size_t)R + 1) * 6 * 4));
-            LM_TRY(ws.h_pairs.reserve(std::max<size_t>((size_t)npair * 8, 64)));
-            LM_HIP(hipMemcpyAsync(ws.h_rbox.p, ws.rbox.p, ((size_t)R + 1) * 6 * 4, hipMemcpyDeviceToHost, s));
-            if (npair) LM_HIP(hipMemcpyAsync(ws.h_pairs.p, ws.pairs.p, (size_t)npair * 8, hipMemcpyDeviceToHost, s));
-            if (!((size_t)R > g_r || nrec > g_n)) LM_HIP(hipStreamSynchronize(s));
         }
         if ((size_t)R > g_r || nrec > g_n) {  // the tables are complete on the device, the guess of what to fetch was short (first volume)
             LM_TRY(ws.h_area.reserve(((size_t)R + 1) * 4));
@@ -346,11 +360,11 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
             if (nrec) LM_HIP(hipMemcpyAsync(ws.h_recs.p, ws.recs.p, (size_t)nrec * sizeof(BoundaryRec), hipMemcpyDeviceToHost, s));
             LM_HIP(hipStreamSynchronize(s));
         }
+        g_r_used = g_r;
         break;
     }
     ws.last_regions = R;
     ws.last_records = nrec;
-    ws.last_pairs = npair;
     info.regions = R;
     info.boundary_records = nrec;
     area = ws.h_area.as<int>();
@@ -379,6 +393,26 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
     }
     if (graph) {
         // ---- (5) on the region graph: kept component of every label, its bounding box; then per label the hole fill on its box
+        LM_HIP(hipStreamSynchronize(s));  // boxes + diagonal pairs (they ran beside the replay above)
+        npair = (unsigned)hs[3];
+        while (npair > pcap) {  // rare: the pair table was too small -- grow it and repeat that one pass
+            pcap = npair;
+            LM_TRY(ws.pairs.reserve((size_t)pcap * 8));
+            LM_HIP(hipMemsetAsync(pcount_dev, 0, sizeof(unsigned), s));
+            LM_K(diag_pairs(lab, ids, d, ws.pairs.as<unsigned long long>(), pcount_dev, pcap, s));
+            LM_HIP(hipMemcpyAsync(const_cast<int*>(hs) + 3, pcount_dev, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+            LM_HIP(hipStreamSynchronize(s));
+            npair = (unsigned)hs[3];
+            g_p = 0;
+        }
+        if ((size_t)R > g_r_used || npair > g_p) {
+            LM_TRY(ws.h_rbox.reserve(((size_t)R + 1) * 6 * 4));
+            LM_TRY(ws.h_pairs.reserve(std::max<size_t>((size_t)npair * 8, 64)));
+            LM_HIP(hipMemcpyAsync(ws.h_rbox.p, ws.rbox.p, ((size_t)R + 1) * 6 * 4, hipMemcpyDeviceToHost, s));
+            if (npair) LM_HIP(hipMemcpyAsync(ws.h_pairs.p, ws.pairs.p, (size_t)npair * 8, hipMemcpyDeviceToHost, s));
+            LM_HIP(hipStreamSynchronize(s));
+        }
+        ws.last_pairs = npair;
         std::vector<uint8_t> keeplut;
         int lbox[256][6];
         bool kept[256];

@@ -35,7 +35,8 @@ hipError_t boundary_records(const int* ids, Dims d, BoundaryRec* recs, unsigned*
 hipError_t apply_lut(const int* ids, const uint8_t* lut, uint8_t* out, size_t nvox, hipStream_t s);
 
 // ---- the second labelling on the region graph (post_engine.hip: postprocess, N > 1)
-// region_stats + box[id][6] = {zmin, ymin, xmin, zmax, ymax, xmax} of every region with id <= cap (box: 6 * (cap + 1) ints, preset here)
+// region_stats + box[id][6] = {zmin, ymin, xmin, zmax, ymax, xmax} of every region with id <= cap (box: 6 * (cap + 1) ints, preset here);
+// area == nullptr: the boxes only (area / labval untouched)
 hipError_t region_stats_box(const int* ids, const uint8_t* lab, int* area, uint8_t* labval, int* box, Dims d, hipStream_t s, int cap);
 // (smaller id << 32 | larger id) of regions with voxels that touch diagonally (26- but not 6-adjacent); duplicates possible;
 // *count_dev is raised for every pair, stored or not (cap)

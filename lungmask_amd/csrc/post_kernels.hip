@@ -812,7 +812,7 @@ __global__ __launch_bounds__(TPB) void region_stats_box_kernel(const int* __rest
             const unsigned long long higher = lane == 63 ? 0ull : (heads >> (lane + 1));
             const int len = higher ? __ffsll((long long)higher) : 64 - lane;
             const int z = (int)(q / (unsigned)d.H), y = (int)(q - (unsigned)z * (unsigned)d.H);
-            labval[id] = lab[v];
+            if (area != nullptr) labval[id] = lab[v];
             unsigned h = ((unsigned)id * 2654435761u) >> 22;
             int slot = -1;
             for (int probe = 0; probe < 8; ++probe) {
@@ -832,7 +832,7 @@ __global__ __launch_bounds__(TPB) void region_stats_box_kernel(const int* __rest
                 if (y > hb[4][slot]) atomicMax(&hb[4][slot], y);
                 if (x + len - 1 > hb[5][slot]) atomicMax(&hb[5][slot], x + len - 1);
             } else {  // table full around this slot: straight to memory
-                atomicAdd(&area[id], len);
+                if (area != nullptr) atomicAdd(&area[id], len);
                 int* b = box + 6 * (size_t)id;
                 gmin(b + 0, z); gmin(b + 1, y); gmin(b + 2, x);
                 gmax(b + 3, z); gmax(b + 4, y); gmax(b + 5, x + len - 1);
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(TPB) void region_stats_box_kernel(const int* __rest
     __syncthreads();
     for (int i = threadIdx.x; i < HS; i += blockDim.x) {
         if (hkey[i] == H_EMPTY || !hcnt[i]) continue;
-        atomicAdd(&area[hkey[i]], hcnt[i]);
+        if (area != nullptr) atomicAdd(&area[hkey[i]], hcnt[i]);
         int* b = box + 6 * (size_t)hkey[i];
         gmin(b + 0, hb[0][i]); gmin(b + 1, hb[1][i]); gmin(b + 2, hb[2][i]);
         gmax(b + 3, hb[3][i]); gmax(b + 4, hb[4][i]); gmax(b + 5, hb[5][i]);

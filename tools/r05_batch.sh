@@ -1,7 +1,8 @@
 mkdir -p gpurun_out
-LIBS="lungmask_amd/_ab/lib_nodpp.so lungmask_amd/liblungmask_hip.so"
-timeout 400 python tools/ab_forward.py $LIBS 2>&1 | grep -v amdgpu.ids > gpurun_out/r05b_ab_forward.log; cat gpurun_out/r05b_ab_forward.log
-timeout 400 python tools/nn_perf_ab.py $LIBS 2>&1 | grep -v amdgpu.ids > gpurun_out/r05b_nn_perf_ab.log; grep -E "H256|sum|ms per" gpurun_out/r05b_nn_perf_ab.log
-timeout 300 python tools/host_boundary.py 2>&1 | grep -v amdgpu.ids | tail -12 > gpurun_out/r05b_host_boundary.log; cat gpurun_out/r05b_host_boundary.log
-timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>gpurun_out/r05b_bench_err.log | tail -1 > gpurun_out/r05b_bench.json; cut -c1-300 gpurun_out/r05b_bench.json
-timeout 900 python -m pytest tests/test_gpu_apply.py tests/test_gpu_forward.py -m gpu -x -q -rs > gpurun_out/r05b_pytest_gpu.log 2>&1; tail -4 gpurun_out/r05b_pytest_gpu.log
+(LM_POST_GRAPH=0 timeout 300 python tools/post_timing.py 2>&1 | grep -E "lm_postprocess|info" | tail -4; timeout 300 python tools/post_timing.py 2>&1 | grep -E "lm_postprocess|info" | tail -4) > gpurun_out/r05c_post_timing.log; cat gpurun_out/r05c_post_timing.log
+timeout 300 python tools/step_timeline.py 2>&1 | grep -v amdgpu.ids | tail -12 > gpurun_out/r05c_step_timeline.log; tail -6 gpurun_out/r05c_step_timeline.log
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --host-steps 0 2>gpurun_out/r05c_bench_err.log | tail -1 > gpurun_out/r05c_bench.json; cut -c1-200 gpurun_out/r05c_bench.json
+LM_POST_GRAPH=0 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --host-steps 0 2>>gpurun_out/r05c_bench_err.log | tail -1 > gpurun_out/r05c_bench_voxel_form.json; cut -c1-200 gpurun_out/r05c_bench_voxel_form.json
+timeout 300 python bench.py --config 4 --steps 5 --warmup 2 --no-cpu-baseline --host-steps 0 2>>gpurun_out/r05c_bench_err.log | tail -1 > gpurun_out/r05c_bench_config4.json; cut -c1-200 gpurun_out/r05c_bench_config4.json
+LM_POST_GRAPH=0 timeout 300 python bench.py --config 4 --steps 5 --warmup 2 --no-cpu-baseline --host-steps 0 2>>gpurun_out/r05c_bench_err.log | tail -1 > gpurun_out/r05c_bench_config4_voxel_form.json; cut -c1-200 gpurun_out/r05c_bench_config4_voxel_form.json
+timeout 1200 python -m pytest tests/test_gpu_prepost.py tests/test_gpu_fullsize.py -m gpu -x -q -rs > gpurun_out/r05c_pytest_gpu.log 2>&1; grep -E "passed|failed|error" gpurun_out/r05c_pytest_gpu.log | tail -3

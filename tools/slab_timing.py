@@ -7,18 +7,25 @@ from lungmask_amd import synthetic as uo; po = uo
 from lungmask_amd import _native as nat
 from lungmask_amd.pipeline import shard_bounds
 
+HEAD = sys.argv[1] if len(sys.argv) > 1 else "lunglike"  # (round 4 measured on the random head's 899-region volume: VERDICT r04 #10)
 eng = nat.Engine(0)
-eng.load_state_dict(0, uo.synthetic_state_dict(3))
-N0 = 300
-vol = po.phantom(N0, 512, 512, seed=2024)
-labs = []
-for i in range(0, N0, 100):
-    xf = eng.preprocess(vol[i:i + 100])[1]
-    labs.append(eng.forward(0, xf[:, None], want_logp=False)[0])
-lab0 = np.concatenate(labs)
+eng.load_state_dict(0, uo.synthetic_state_dict(3, head=HEAD))
+
+
+def network_labels(n_total):
+    """argmax labels (256 x 256) of the n_total-slice bench phantom -- for world w the ONE volume of 300 w slices that config 5 shards
+    (its lungs span the ranks' slabs), not w copies of the 300-slice one."""
+    labs = []
+    for i in range(0, n_total, 100):
+        vol = po.phantom(n_total, 512, 512, seed=2024, z0=i, z1=min(i + 100, n_total))
+        xf = eng.preprocess(vol)[1]
+        labs.append(eng.forward(0, xf[:, None], want_logp=False)[0])
+    return np.concatenate(labs)
+
+
 extra = [nat.Engine(0) for _ in range(7)]
 for world in (1, 2, 4, 8):
-    lab = np.concatenate([lab0] * world)  # weak scaling: 300 slices per rank
+    lab = network_labels(300 * world)  # weak scaling: 300 slices per rank
     N = lab.shape[0]
     d = eng.to_device(lab)
     for _ in range(2):
