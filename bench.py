@@ -343,7 +343,7 @@ def main():
                          "like production's for the 3-D post-processing), or the seeded random one of rounds 1-3")
     ap.add_argument("--post", default="auto", choices=["auto", "slab", "gathered"],
                     help="N>1 post-processing: slab-sharded, or label all-gather + redundant whole-volume pass; auto (default) = the pipeline's own "
-                         "choice by world size: slab from three ranks on (profiles/r04r_slab_timing.log)")
+                         "choice by world size: slab from four ranks on (profiles/r05d_slab_timing_lunglike.log)")
     ap.add_argument("--dist", default="torch", choices=["torch", "native"],
                     help="N>1 collectives: torch.distributed (backend nccl = RCCL) or the engine's own RCCL communicator behind the C ABI (lm_dist_*)")
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2], help="forward lanes (2: consecutive batches overlap on two streams)")

@@ -153,60 +153,73 @@ void replay_merge(int R, const int* area, const uint8_t* lv, const BoundaryRec* 
 }
 
 // utils.py:355-356 / :390-404 on the region graph: the components of the mapped volume are unions of first-pass regions that are
-// 26-adjacent and carry the same mapped label (the 6-adjacency is in the boundary records, the diagonal rest in `pairs`).  For
-// every label the largest component is kept (area; on ties the component whose first voxel comes LAST in raster order -- regions
-// are numbered by their first voxel, so that is the component with the largest smallest id: the rule of component_max's key).
-// keeplut[region] = its label when the region belongs to its label's kept component, else 0; lbox[label] = that component's box.
-static void graph_components(int R, const int* area, const std::vector<uint8_t>& lut, const BoundaryRec* recs, size_t nrecs, const unsigned long long* pairs,
-                             size_t npairs, const int* rbox, int dropped_label, std::vector<uint8_t>& keeplut, int lbox[256][6], bool kept[256]) {
-    static thread_local std::vector<int> uf;
-    static thread_local std::vector<long long> carea;
-    uf.resize(R + 1);
-    std::iota(uf.begin(), uf.end(), 0);
-    auto find = [&](int a) {
+// 26-adjacent and carry the same mapped label (the 6-adjacency is in the boundary records, the diagonal rest in `pairs`).
+struct RegionGraph {
+    // union-find over the regions; the root of a set is its SMALLEST id (= the region that holds the component's first voxel)
+    std::vector<int> uf;
+    std::vector<long long> carea;
+    const std::vector<uint8_t>* lut = nullptr;
+    int R = 0;
+    int find(int a) {
         while (uf[a] != a) {
             uf[a] = uf[uf[a]];
             a = uf[a];
         }
         return a;
-    };
-    auto unite = [&](int a, int b) {  // the root of a set is its SMALLEST id (= the region with the component's first voxel)
-        if (a < 1 || b < 1 || a > R || b > R || !lut[a] || lut[a] != lut[b]) return;
+    }
+    void unite(int a, int b) {
+        const std::vector<uint8_t>& l = *lut;
+        if (a < 1 || b < 1 || a > R || b > R || !l[a] || l[a] != l[b]) return;
         a = find(a);
         b = find(b);
         if (a == b) return;
         if (a < b) uf[b] = a;
         else uf[a] = b;
-    };
-    for (size_t j = 0; j < nrecs; ++j)
-        for (int k = 0; k < 6 && recs[j].nb[k]; ++k) unite(recs[j].atom, recs[j].nb[k]);
-    for (size_t j = 0; j < npairs; ++j) unite((int)(pairs[j] >> 32), (int)(pairs[j] & 0xffffffffull));
-    carea.assign(R + 1, 0);
-    for (int a = 1; a <= R; ++a)
-        if (lut[a]) carea[find(a)] += area[a];
-    int best[256];
-    for (int i = 0; i < 256; ++i) {
-        best[i] = 0;
-        kept[i] = false;
-        lbox[i][0] = lbox[i][1] = lbox[i][2] = 0x7fffffff;
-        lbox[i][3] = lbox[i][4] = lbox[i][5] = -1;
     }
-    for (int a = 1; a <= R; ++a) {
-        if (!lut[a] || uf[a] != a) continue;
-        const int L = lut[a], b = best[L];
-        if (!b || carea[a] > carea[b] || (carea[a] == carea[b] && a > b)) best[L] = a;
+    // phase A (needs only the boundary records: runs while the boxes / pairs kernels are still on the device): the 6-adjacency
+    void begin(int R_, const std::vector<uint8_t>& lut_, const BoundaryRec* recs, size_t nrecs) {
+        R = R_;
+        lut = &lut_;
+        uf.resize((size_t)R + 1);
+        std::iota(uf.begin(), uf.end(), 0);
+        for (size_t j = 0; j < nrecs; ++j)
+            for (int k = 0; k < 6 && recs[j].nb[k]; ++k) unite(recs[j].atom, recs[j].nb[k]);
     }
-    keeplut.assign((size_t)R + 1, 0);
-    for (int a = 1; a <= R; ++a) {
-        const int L = lut[a];
-        if (!L || L == dropped_label || find(a) != best[L]) continue;
-        keeplut[a] = (uint8_t)L;
-        kept[L] = true;
-        const int* b = rbox + 6 * (size_t)a;
-        for (int k = 0; k < 3; ++k) lbox[L][k] = std::min(lbox[L][k], b[k]);
-        for (int k = 3; k < 6; ++k) lbox[L][k] = std::max(lbox[L][k], b[k]);
+    // phase B: the diagonal rest of the 26-adjacency, then for every label the largest component (area; on ties the component whose
+    // first voxel comes LAST in raster order -- regions are numbered by their first voxel, so that is the component with the
+    // largest smallest id: the rule of component_max's key).  keeplut[region] = its label when the region belongs to its label's
+    // kept component, else 0; lbox[label] = that component's bounding box.
+    void finish(const int* area, const unsigned long long* pairs, size_t npairs, const int* rbox, int dropped_label, std::vector<uint8_t>& keeplut, int lbox[256][6],
+                bool kept[256]) {
+        const std::vector<uint8_t>& l = *lut;
+        for (size_t j = 0; j < npairs; ++j) unite((int)(pairs[j] >> 32), (int)(pairs[j] & 0xffffffffull));
+        carea.assign((size_t)R + 1, 0);
+        for (int a = 1; a <= R; ++a)
+            if (l[a]) carea[find(a)] += area[a];
+        int best[256];
+        for (int i = 0; i < 256; ++i) {
+            best[i] = 0;
+            kept[i] = false;
+            lbox[i][0] = lbox[i][1] = lbox[i][2] = 0x7fffffff;
+            lbox[i][3] = lbox[i][4] = lbox[i][5] = -1;
+        }
+        for (int a = 1; a <= R; ++a) {
+            if (!l[a] || uf[a] != a) continue;
+            const int L = l[a], b = best[L];
+            if (!b || carea[a] > carea[b] || (carea[a] == carea[b] && a > b)) best[L] = a;
+        }
+        keeplut.assign((size_t)R + 1, 0);
+        for (int a = 1; a <= R; ++a) {
+            const int L = l[a];
+            if (!L || L == dropped_label || find(a) != best[L]) continue;
+            keeplut[a] = (uint8_t)L;
+            kept[L] = true;
+            const int* b = rbox + 6 * (size_t)a;
+            for (int k = 0; k < 3; ++k) lbox[L][k] = std::min(lbox[L][k], b[k]);
+            for (int k = 3; k < 6; ++k) lbox[L][k] = std::max(lbox[L][k], b[k]);
+        }
     }
-}
+};
 
 int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spare_p, int n_spare, int skip_below, int range_slot, bool* range_tripped) {
     if (range_tripped) *range_tripped = false;
@@ -393,7 +406,9 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
     }
     if (graph) {
         // ---- (5) on the region graph: kept component of every label, its bounding box; then per label the hole fill on its box
-        LM_HIP(hipStreamSynchronize(s));  // boxes + diagonal pairs (they ran beside the replay above)
+        static thread_local RegionGraph rg;
+        rg.begin(R, lut, recs, nrec);     // (still beside the boxes / pairs kernels)
+        LM_HIP(hipStreamSynchronize(s));  // boxes + diagonal pairs
         npair = (unsigned)hs[3];
         while (npair > pcap) {  // rare: the pair table was too small -- grow it and repeat that one pass
             pcap = npair;
@@ -416,7 +431,7 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
         std::vector<uint8_t> keeplut;
         int lbox[256][6];
         bool kept[256];
-        graph_components(R, area, lut, recs, nrec, ws.h_pairs.as<unsigned long long>(), npair, ws.h_rbox.as<int>(), dropped_label, keeplut, lbox, kept);
+        rg.finish(area, ws.h_pairs.as<unsigned long long>(), npair, ws.h_rbox.as<int>(), dropped_label, keeplut, lbox, kept);
         const double t_graph = ms_now();
         keeplut.resize(std::max<size_t>(keeplut.size(), 1), 0);
         LM_TRY(ws.lut.reserve(keeplut.size()));

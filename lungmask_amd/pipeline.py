@@ -6,10 +6,10 @@ slice-wise (utils.py:48-51, mask.py:173-187) -> contiguous slice blocks per rank
 weights replicated, NO collective.  The 3-D post-processing (utils.py:272-358) spans
 the whole volume; two forms:
 
-* slab-sharded (default from three ranks on): every rank post-processes its own slab and the slabs are tied
+* slab-sharded (default from four ranks on): every rank post-processes its own slab and the slabs are tied
   together by six small all-gathers of face planes / atom tables (`lm_slab_*`,
   csrc/slab_engine.hip) -- the voxel passes scale with 1/world;
-* gathered (`sharded_post=False`, the default with one or two ranks, and whenever a rank has no slice): ONE all-gather of the
+* gathered (`sharded_post=False`, the default below four ranks, and whenever a rank has no slice): ONE all-gather of the
   uint8 256x256 label shards (64 KiB/slice), then every rank runs the identical
   deterministic whole-volume post-processing (the serial fraction of weak scaling).
 
@@ -157,9 +157,11 @@ class ShardedPipeline:
         self.device = torch.device(device)
         self.world = dist.get_world_size() if dist is not None else 1
         self.rank = dist.get_rank() if dist is not None else 0
-        # None: by world size.  The slab protocol's fixed part (six exchanges, three host table merges) only pays from three ranks
-        # on -- below that the redundant whole-volume pass on the gathered labels is cheaper (tools/slab_timing.py)
-        self.sharded_post = (self.world >= 3) if sharded_post is None else bool(sharded_post)
+        # None: by world size.  The slab protocol's fixed part (six exchanges, three host table merges) only pays from four ranks
+        # on -- below the crossover the redundant whole-volume pass on the gathered labels is cheaper (tools/slab_timing.py)
+        # (round 5, lung-like labels of ONE 300 w-slice volume, profiles/r05d_slab_timing_lunglike.log: whole-volume pass 2.7 / 5.0 / 9.1 ms
+        # at 600 / 1200 / 2400 slices against 3.7 / 4.7 / 6.5 ms per rank for the protocol at 2 / 4 / 8 ranks: the crossover is at four)
+        self.sharded_post = (self.world >= 4) if sharded_post is None else bool(sharded_post)
         self._buf = {}
         self._slab_caps = {}   # agreed capacity (ints) of the variable-length table exchange of every protocol round, per volume geometry
         self._slab_key = None

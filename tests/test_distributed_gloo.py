@@ -330,7 +330,7 @@ def test_lminferer_shards_over_engines_in_one_process():
         inf.close()
         # ---- fused mode (a second 3-class model stands in for the fill model), gathered post-processing, a result array of its own
         inf = LMInferer(modelname="LTRCLobes", fillmodel="R231", state_dict=sd_l, fill_state_dict=sd_r, engines=engs, batch_size=2, resolution=(32, 32))
-        assert not inf._shard.pipes[0].sharded_post  # (the default below three ranks)
+        assert not inf._shard.pipes[0].sharded_post  # (the default below four ranks)
         expect_f = po.fuse(expect, one(1))
         out_f = inf.apply(vol)
         assert out_f.dtype == np.uint8 and np.array_equal(out_f, expect_f) and not np.shares_memory(out_f, mine)

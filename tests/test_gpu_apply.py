@@ -557,14 +557,14 @@ def test_lminferer_over_several_engines_in_one_process(gpu_engine, fused):
     vol = po.phantom(25, 512, 512, seed=31)
     single = LMInferer(engine=gpu_engine, **kw)
     expect = single.apply(vol).copy()
-    for sharded_post in (None, False):
+    for sharded_post in (True, False):
         inf = LMInferer(device_ids=[0, 0, 0], sharded_post=sharded_post, **kw)
         assert inf._shard.world == 3
         out = inf.apply(vol)
         assert out.dtype == np.uint8 and np.array_equal(out, expect), (sharded_post, int((out != expect).sum()))
         out2 = inf.apply(vol[:7])  # fewer slices than before, other blocks (3 + 2 + 2)
         assert np.array_equal(out2, single.apply(vol[:7])) and not np.shares_memory(out, out2)
-        if sharded_post is None:
+        if sharded_post:
             direction = (1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, -1.0)  # LPI
             axes, flips = volume_io.lps_transform(direction)
             img = volume_io.Volume(np.ascontiguousarray(volume_io.apply_transform(vol, *volume_io.inverse_transform(axes, flips))), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0), direction)
