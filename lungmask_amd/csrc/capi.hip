@@ -69,6 +69,7 @@ void lm_engine_destroy(lm_engine* e) {
     if (e->range_flag_host) (void)hipHostFree(e->range_flag_host);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     if (e->tail_ready) (void)hipEventDestroy(e->tail_ready);
+    if (e->mid_ready) (void)hipEventDestroy(e->mid_ready);
     if (e->pre_fork) (void)hipEventDestroy(e->pre_fork);
     if (e->pre_tail_done) (void)hipEventDestroy(e->pre_tail_done);
     e->nn.release();
@@ -414,7 +415,10 @@ int lm_apply_host_ex(lm_engine* e, int slot, int fill_slot, const void* vol_host
     // written back), so that the copy back at the end does not take the page faults of a freshly allocated buffer.  The
     // caller's array is only ever overwritten by the final copy of a successful call; on any error it is left as it was.
     if (batch_size <= 0) batch_size = 20;
-    const int head = (e->n_streams > 1 ? 2 : 1) * batch_size;
+    // two lanes: the head is the main stream's first batch, the second lane's first batch follows as a piece of its own (`mid`)
+    const bool two_lanes = e->n_streams > 1 && e->stream2 != nullptr;
+    const int mid = (two_lanes && n > 2 * batch_size) ? 2 * batch_size : 0;
+    const int head = mid ? batch_size : (two_lanes ? 2 : 1) * batch_size;
     bool split = n > head;
     if (split && !e->copy_stream) {
         if (hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->tail_ready, hipEventDisableTiming) != hipSuccess) {
@@ -425,6 +429,12 @@ int lm_apply_host_ex(lm_engine* e, int slot, int fill_slot, const void* vol_host
     const bool out_pinned = host_range_is_pinned(out_host, nvox);
     const bool threaded = e->helper.start();  // false: no thread could be created -- one copy on the main stream, no page touching
     if (!threaded) split = false;
+    if (split && mid && !e->mid_ready && hipEventCreateWithFlags(&e->mid_ready, hipEventDisableTiming) != hipSuccess) {
+        set_error("lm_apply_host: creating the copy events failed");
+        return LM_ERR_DEVICE;
+    }
+    const int tail0 = (split && mid) ? mid : head;  // first slice of the tail piece
+    e->mid_enqueued.store(0, std::memory_order_release);
     static const bool timing = [] { const char* v = getenv("LM_HOST_TIMING"); return v && v[0] == '1'; }();  // stderr breakdown of this call
     const auto t_start = std::chrono::steady_clock::now();
     auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
@@ -436,11 +446,18 @@ int lm_apply_host_ex(lm_engine* e, int slot, int fill_slot, const void* vol_host
             if (split) {
                 terr = hipSetDevice(e->device);
                 // (a pageable source makes this call return only when the data has been staged: that is why it lives on this thread)
-                if (terr == hipSuccess)
+                if (terr == hipSuccess && tail0 > head) {  // lane 1's first batch, in front of the tail
                     terr = hipMemcpyAsync(reinterpret_cast<char*>(e->app.vol.p) + (size_t)head * slice * esz, reinterpret_cast<const char*>(vol_host) + (size_t)head * slice * esz,
-                                          (size_t)(n - head) * slice * esz, hipMemcpyHostToDevice, e->copy_stream);
+                                          (size_t)(tail0 - head) * slice * esz, hipMemcpyHostToDevice, e->copy_stream);
+                    if (terr == hipSuccess) terr = hipEventRecord(e->mid_ready, e->copy_stream);
+                    e->mid_enqueued.store(terr == hipSuccess ? 1 : -1, std::memory_order_release);
+                }
+                if (terr == hipSuccess)
+                    terr = hipMemcpyAsync(reinterpret_cast<char*>(e->app.vol.p) + (size_t)tail0 * slice * esz, reinterpret_cast<const char*>(vol_host) + (size_t)tail0 * slice * esz,
+                                          (size_t)(n - tail0) * slice * esz, hipMemcpyHostToDevice, e->copy_stream);
                 if (terr == hipSuccess) terr = hipEventRecord(e->tail_ready, e->copy_stream);
             }
+            if (terr != hipSuccess) e->mid_enqueued.store(-1, std::memory_order_release);
             e->tail_enqueued.store(terr == hipSuccess ? 1 : -1, std::memory_order_release);
             t_tail = ms_since(t_start);
             // (Pinning the caller's array here with hipHostRegister makes the copy back 0.4 ms faster -- tools/host_pin_probe.py -- but an
@@ -463,8 +480,10 @@ int lm_apply_host_ex(lm_engine* e, int slot, int fill_slot, const void* vol_host
         rc = LM_ERR_DEVICE;
     } else {
         e->head_slices = split ? head : 0;
+        e->mid_slices = split ? mid : 0;
         rc = apply_volume(e, slot, fill_slot, e->app.vol.p, dtype, n, h, w, batch_size, volume_postprocessing, e->app.out.as<uint8_t>());
         e->head_slices = 0;
+        e->mid_slices = 0;
     }
     const double t_apply = ms_since(t_start);
     if (threaded) e->helper.wait();

@@ -265,6 +265,12 @@ struct lm_engine {
     // set by the copying thread once tail_ready has been recorded (1) or the copy failed (-1): the hot path must not enqueue
     // its wait on an event that has not been recorded yet (that would be a no-op)
     std::atomic<int> tail_enqueued{0};
+    // Round 5: with two forward lanes the head is ONE batch (the main stream's first) and the second lane's first batch -- slices
+    // [head_slices, mid_slices) -- arrives as a piece of its own in front of the tail: `mid_ready` is recorded behind it and lane 1's
+    // stream pre-processes it itself, so the first kernel starts after 10 MB have crossed the link instead of 21.  mid_slices == 0: no such piece.
+    hipEvent_t mid_ready = nullptr;
+    int mid_slices = 0;
+    std::atomic<int> mid_enqueued{0};
     lm::HostHelper helper;
     unsigned* range_flag = nullptr;       // device word of the f16 range guard (ConvParamsH3::range_flag)
     unsigned* range_flag_host = nullptr;  // pinned copy

@@ -606,6 +606,20 @@ int inference(lm_engine* e, int slot, const void* vol, int dtype, int n, int h, 
     }
     if (head < n) LM_HIP(hipEventRecord(e->pre_fork, e->stream));  // everything the caller / the previous volume enqueued
     if (!have_pre) LM_TRY(preprocess(0, head, e->stream));
+    // lm_apply_host with two lanes: the second lane's first batch arrives as a piece of its own (engine.h: mid_slices) and that lane's
+    // stream pre-processes it itself, behind the piece's copy -- the tail (and its pre-processing on the copy stream) starts at `mid`
+    const int mid = (arriving && !have_pre && lanes == 2 && e->mid_slices > head && e->mid_slices < n) ? e->mid_slices : 0;
+    if (mid) {
+        while (e->mid_enqueued.load(std::memory_order_acquire) == 0) std::this_thread::yield();
+        if (e->mid_enqueued.load(std::memory_order_acquire) < 0) {
+            set_error("lm_apply_host: copying the volume to the device failed");
+            return LM_ERR_DEVICE;
+        }
+        LM_HIP(hipStreamWaitEvent(e->stream2, e->mid_ready, 0));
+        LM_HIP(hipStreamWaitEvent(e->stream2, e->pre_fork, 0));
+        LM_TRY(preprocess(head, mid - head, e->stream2));
+    }
+    const int tail0 = mid ? mid : head;
     auto gate = [&](hipEvent_t* ev) -> int {
         if (arriving) {
             while (e->tail_enqueued.load(std::memory_order_acquire) == 0) std::this_thread::yield();  // normally long done
@@ -616,13 +630,13 @@ int inference(lm_engine* e, int slot, const void* vol, int dtype, int n, int h, 
         }
         // (the copy stream already holds lm_apply_host's copy of the tail, if any: stream order)
         LM_HIP(hipStreamWaitEvent(e->copy_stream, e->pre_fork, 0));
-        LM_TRY(preprocess(head, n - head, e->copy_stream));
+        LM_TRY(preprocess(tail0, n - tail0, e->copy_stream));
         LM_HIP(hipEventRecord(e->pre_tail_done, e->copy_stream));
         *ev = e->pre_tail_done;
         return LM_OK;
     };
     // mask.py:173-187
-    if (head < n) LM_TRY(forward_batches(e, slot, a.xf.as<float>(), n, R, R, batch, a.labels.as<uint8_t>(), head, gate));
+    if (head < n) LM_TRY(forward_batches(e, slot, a.xf.as<float>(), n, R, R, batch, a.labels.as<uint8_t>(), tail0, gate));
     else LM_TRY(forward_batches(e, slot, a.xf.as<float>(), n, R, R, batch, a.labels.as<uint8_t>()));
     // The f16 range flag of the forward passes is read back once per volume: inside the post-processing's first round trip when
     // there is one, on its own otherwise.  When it is set the model is now pinned to the exact-fp32 kernels: the whole volume
