@@ -167,7 +167,7 @@ class ChipSampler:
     the amdgpu hwmon files (one small read per value), else `rocm-smi --json` (a process per sample: coarse).  Failures are
     recorded in the line, never raised; nothing here touches the GPU's queues."""
 
-    def __init__(self, index, period=0.05):
+    def __init__(self, index, period=0.05, pci_bus_id=None):
         import glob
         import threading
 
@@ -187,6 +187,11 @@ class ChipSampler:
                     continue
                 cards.append((os.path.realpath(os.path.join(c, "device")), c))
             cards.sort()
+            # the card of THIS process's device: by PCI address when the runtime gives one (a box may show more cards in sysfs than
+            # the container has devices: r05e sampled an idle neighbour at 114 MHz), else by position
+            if pci_bus_id:
+                hit = [i for i, c in enumerate(cards) if c[0].lower().endswith(pci_bus_id.lower())]
+                index = hit[0] if hit else len(cards)
             if index < len(cards):
                 hw = sorted(glob.glob(os.path.join(cards[index][1], "device/hwmon/hwmon*")))
                 if hw:
@@ -194,7 +199,7 @@ class ChipSampler:
                     fq = os.path.join(hw[0], "freq1_input") if os.path.exists(os.path.join(hw[0], "freq1_input")) else None
                     if pw or fq:
                         self.files = (pw, fq)
-                        self.source = f"sysfs hwmon ({cards[index][0].rsplit('/', 1)[-1]})"
+                        self.source = f"sysfs hwmon ({cards[index][0].rsplit('/', 1)[-1]}" + (", matched by PCI address)" if pci_bus_id else ", by position)")
         except Exception as e:  # noqa: BLE001
             self.err = repr(e)[:200]
         self.index = index
@@ -477,7 +482,19 @@ def main():
             return float(tt.item())
         return group.max(v) if group is not None else v
 
-    sampler = ChipSampler(local_rank) if (rank == 0 and not emu) else None
+    sampler = None
+    if rank == 0 and not emu:
+        pci = None
+        try:  # "dddd:bb:dd.f" of the HIP device (hipDeviceGetPCIBusId through the runtime torch already loaded)
+            import ctypes
+
+            buf = ctypes.create_string_buffer(64)
+            hip = ctypes.CDLL("libamdhip64.so")
+            if hip.hipDeviceGetPCIBusId(buf, 64, local_rank) == 0:
+                pci = buf.value.decode()
+        except Exception:  # noqa: BLE001
+            pci = None
+        sampler = ChipSampler(local_rank, pci_bus_id=pci)
     if sampler is not None:
         sampler.start()
     # ---- the contract's timed region: exactly --steps steps between barrier + synchronise on both sides, max over ranks
