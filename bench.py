@@ -24,7 +24,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP3
 PEAK_F16_MFMA_TFLOPS = 2500.0  # same table: Peak BF16/FP16 MFMA, dense
 # What the matrix pipes SUSTAIN on this network's operand statistics (tools/ubench/mfma_power.hip, the conv kernel's own
 # instruction pattern on full-range split operands, no memory traffic at all): the chip clocks to its power budget, 2.37 GHz
-# on zeros but ~1.6 GHz on real data.  profiles/r02d_mfma_power.log
+# on zeros but ~1.6 GHz on real data.  profiles/history/r02d_mfma_power.log
 SUSTAINED_F16_MFMA_TFLOPS = 1737.0
 # algorithmic FLOP per slice, SURVEY.md Appendix A (256x256): R231 (3 classes), LTRCLobes (6 classes)
 FLOP_PER_SLICE = {3: 96.200556544e9, 6: 96.225722368e9}
@@ -618,7 +618,7 @@ def main():
                 "sustained_mfma_ceiling_tflops": SUSTAINED_F16_MFMA_TFLOPS if h3 else None,
                 "executed_frac_of_sustained_ceiling": round(ach * 3 / SUSTAINED_F16_MFMA_TFLOPS, 4) if h3 else None,
                 "ceiling_note": "the data sheet peak assumes 2.4 GHz; on full-range operands the matrix pipes alone (no memory traffic) sustain "
-                                "1737 TFLOP/s at ~1.6 GHz under the power budget (tools/ubench/mfma_power.hip, profiles/r02d_mfma_power.log)" if h3 else None,
+                                "1737 TFLOP/s at ~1.6 GHz under the power budget (tools/ubench/mfma_power.hip, profiles/history/r02d_mfma_power.log)" if h3 else None,
                 "traffic": traffic,
                 "traffic_unit": "HBM bytes/launch, launch-weighted over the same 17 launches per batch as algorithmic_bytes_per_launch; NOT measured in this "
                                 f"run: read from the committed rocprofv3 PMC summary {traffic_src} (separate FETCH_SIZE / WRITE_SIZE passes of "

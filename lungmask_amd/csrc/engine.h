@@ -253,7 +253,7 @@ struct lm_engine {
     lm::SlabState slab;
     lm::Profiler prof;
     int precision = 1;  // 1 (default): split-f16 3-product; 0: exact fp32 matrix ops (lm_set_precision)
-    int fusion = 11;    // (default: bits 0 and 3; bit 2, split-K, measured slower -- profiles/r04n_splitk_1x1_ab.log) lm_set_fusion: bit 0 first conv in conv 2's loader, bit 1 bilinear x2 in the decoder conv's loader, bit 2 split-K 1x1, bit 3 head in the last conv's epilogue
+    int fusion = 11;    // (default: bits 0 and 3; bit 2, split-K, measured slower -- profiles/history/r04n_splitk_1x1_ab.log) lm_set_fusion: bit 0 first conv in conv 2's loader, bit 1 bilinear x2 in the decoder conv's loader, bit 2 split-K 1x1, bit 3 head in the last conv's epilogue
     char* zero_page = nullptr;
     // lm_apply_host: the volume arrives in two pieces (the first two batches on the main stream, the rest on copy_stream while
     // they are computed); `tail_ready` is recorded behind the second piece, the hot path waits for it before it touches

@@ -594,7 +594,7 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
     const int abl = 0;
 #endif
     // (Running the full-resolution level in sub-batches of 10 / 5 / 4 slices so that its producer -> consumer pairs stay inside the
-    // 256 MB memory-side cache was measured in round 3 and gains nothing -- profiles/r03k_l0_subbatch.log: written data does not
+    // 256 MB memory-side cache was measured in round 3 and gains nothing -- profiles/history/r03k_l0_subbatch.log: written data does not
     // stay there.)
     // ---- encoder (resunet.py:60-64)
     // The first conv (Cin = 1) is computed inside the loader of the second one whenever that conv runs on the persistent split-f16

@@ -1,6 +1,6 @@
 """MFMA utilisation of the conv kernels from raw rocprofv3 counters (ROCm 7.2 has no gfx950 derived metrics):
 
-  python tools/mfma_util.py gpurun_out/prof_r01i profiles/r01i
+  python tools/mfma_util.py gpurun_out/prof_r01i profiles/history/r01i
 
 expects <src>/pmc_sq (SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY
 SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE), <src>/pmc_grbm (GRBM_GUI_ACTIVE GRBM_COUNT) and
