@@ -9,8 +9,9 @@ python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | t
 LM_BENCH_FORCE_DIST=1 python bench.py --steps 3 --no-cpu-baseline --host-steps 0 2>gpurun_out/bench_dist_err.log | tail -1 > gpurun_out/bench_forced_dist_$TAG.txt; cut -c1-200 gpurun_out/bench_forced_dist_$TAG.txt
 LM_BENCH_FORCE_DIST=1 python bench.py --steps 3 --no-cpu-baseline --host-steps 0 --dist native 2>>gpurun_out/bench_dist_err.log | tail -1 > gpurun_out/bench_forced_dist_native_$TAG.txt; cut -c1-200 gpurun_out/bench_forced_dist_native_$TAG.txt
 LM_BENCH_FORCE_DIST=1 python bench.py --steps 3 --no-cpu-baseline --host-steps 0 --post slab 2>>gpurun_out/bench_dist_err.log | tail -1 > gpurun_out/bench_forced_dist_slab_$TAG.txt; cut -c1-200 gpurun_out/bench_forced_dist_slab_$TAG.txt
+LM_BENCH_FORCE_DIST=1 python bench.py --config 4 --steps 2 --no-cpu-baseline --host-steps 0 --dist native --post slab 2>>gpurun_out/bench_dist_err.log | tail -1 > gpurun_out/bench_forced_dist_fused_$TAG.txt; cut -c1-200 gpurun_out/bench_forced_dist_fused_$TAG.txt
 python bench.py --gpus 2 > gpurun_out/bench_gpus2_refusal_$TAG.txt 2>&1; tail -1 gpurun_out/bench_gpus2_refusal_$TAG.txt | cut -c1-200
-python bench.py --steps 10 2>gpurun_out/bench_err.log | tail -1 > gpurun_out/bench_$TAG.json; cut -c1-200 gpurun_out/bench_$TAG.json
+python bench.py --steps 20 --warmup 5 2>gpurun_out/bench_err.log | tail -1 > gpurun_out/bench_$TAG.json; cut -c1-200 gpurun_out/bench_$TAG.json
 for c in 3 4; do python bench.py --config $c --steps 3 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_${TAG}_config$c.json; cut -c1-160 gpurun_out/bench_${TAG}_config$c.json; done
 LM_HOST_TIMING=1 python tools/host_boundary.py 2>&1 | grep -v amdgpu.ids | tail -4 > gpurun_out/host_boundary_$TAG.log; tail -1 gpurun_out/host_boundary_$TAG.log
 python tools/slab_timing.py 2>&1 | grep -v amdgpu.ids > gpurun_out/slab_timing_$TAG.log; tail -4 gpurun_out/slab_timing_$TAG.log
