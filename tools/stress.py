@@ -9,7 +9,7 @@ from lungmask_amd.pipeline import postprocess_slabs_in_process, shard_bounds
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 eng = nat.Engine(0)
-eng.load_state_dict(0, sy.synthetic_state_dict(3))
+eng.load_state_dict(0, sy.synthetic_state_dict(3, head="lunglike"))  # (2 553 regions, 341 merges: the post-processing's region graph has work to do)
 vol = sy.phantom(300, 512, 512, seed=2024)
 d = eng.to_device(vol); o = eng.empty(vol.shape, np.uint8)
 eng.apply_dev(0, d, o); eng.sync()
@@ -20,6 +20,16 @@ for i in range(reps):
     if zlib.crc32(o.download().tobytes()) != ref_crc:
         bad += 1; print("MISMATCH in apply repetition", i, int((o.download() != ref).sum()), flush=True)
 print(f"apply: {reps} repetitions of 300 slices, {bad} differing outputs, {time.time() - t0:.1f} s", flush=True)
+# the host path (three-piece copy-in, scratch result arrays: zero-fill beside the forward, labelled slab copied back)
+from lungmask_amd.mask import LMInferer
+inf = LMInferer(state_dict=sy.synthetic_state_dict(3, head="lunglike"), engine=eng)
+t0 = time.time(); bad = 0; keep = None
+for i in range(max(10, reps // 3)):
+    r = inf.apply(vol)
+    if zlib.crc32(r.tobytes()) != ref_crc:
+        bad += 1; print("MISMATCH in LMInferer.apply repetition", i, int((r != ref).sum()), flush=True)
+    if i % 7 == 0: keep = r  # (held results force other pool blocks)
+print(f"LMInferer.apply: {max(10, reps // 3)} repetitions, {bad} differing outputs, {time.time() - t0:.1f} s", flush=True)
 # labels of the network (before post-processing) with one and two lanes, small and odd batch sizes
 xf = eng.preprocess(vol[:100])[1]
 x = eng.to_device(xf); lab = eng.empty((100, 256, 256), np.uint8)
