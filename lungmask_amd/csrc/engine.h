@@ -136,12 +136,15 @@ struct PostWorkspace {
     DevBuf parent, ids, rank, bgparent, blockcnt, area, labval, recs, lut, mapped, bg, out, scalars, bbox;
     DevBuf rbox, pairs;  // region-graph form of the second labelling: bounding box per region, diagonal adjacency pairs
     hipEvent_t tables_ready = nullptr;  // behind the first read-back (the host replays the merge while the boxes / pairs kernels run)
+    hipEvent_t side_fork = nullptr, side_done = nullptr;  // the boxes / pairs kernels on the second lane's (idle) stream beside part 1
     void release() {
         parent.release(); ids.release(); rank.release(); bgparent.release(); blockcnt.release(); area.release(); labval.release();
         recs.release(); lut.release(); mapped.release(); bg.release(); out.release(); scalars.release(); bbox.release();
         rbox.release(); pairs.release();
         if (tables_ready) (void)hipEventDestroy(tables_ready);
-        tables_ready = nullptr;
+        if (side_fork) (void)hipEventDestroy(side_fork);
+        if (side_done) (void)hipEventDestroy(side_done);
+        tables_ready = side_fork = side_done = nullptr;
         h_area.release(); h_labval.release(); h_recs.release(); h_scalars.release(); h_rbox.release(); h_pairs.release();
     }
 };

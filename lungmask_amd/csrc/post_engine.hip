@@ -295,11 +295,46 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
     const int* area = nullptr;
     const uint8_t* lv = nullptr;
     const BoundaryRec* recs = nullptr;
+    // The boxes / pairs kernels need nothing of steps 2-3: they run on the second forward lane's stream (idle here: the lanes were
+    // joined before the post-processing) BESIDE region_stats / boundary_records, not behind them (LM_POST_SIDE=0: behind, on this stream).
+    static const bool side_ok = [] { const char* v = getenv("LM_POST_SIDE"); return !(v && v[0] == '0'); }();
+    hipStream_t side = (graph && side_ok && e->stream2 != nullptr) ? e->stream2 : s;
+    if (side != s && !ws.side_fork) {
+        LM_HIP(hipEventCreateWithFlags(&ws.side_fork, hipEventDisableTiming));
+        LM_HIP(hipEventCreateWithFlags(&ws.side_done, hipEventDisableTiming));
+    }
+    auto enqueue_graph_inputs = [&](size_t g_r) -> int {  // boxes, diagonal pairs and their speculative read-back, on `side`
+        LM_TRY(ws.rbox.reserve(((size_t)rcap + 1) * 6 * 4));
+        LM_TRY(ws.pairs.reserve((size_t)pcap * 8));
+        {
+            ProfScope ps(e, "post_region_boxes", (double)nvox * 4, side);
+            LM_K(region_stats_box(ids, lab, nullptr, nullptr, ws.rbox.as<int>(), d, side, rcap));
+        }
+        LM_HIP(hipMemsetAsync(pcount_dev, 0, sizeof(unsigned), side));
+        {
+            ProfScope ps(e, "post_diag_pairs", (double)nvox * 2, side);
+            LM_K(diag_pairs(lab, ids, d, ws.pairs.as<unsigned long long>(), pcount_dev, pcap, side));
+        }
+        g_p = tiny ? std::min<size_t>(pcap, 4) : std::min<size_t>(pcap, std::max<size_t>(16384, (size_t)ws.last_pairs + ws.last_pairs / 4 + 1024));
+        LM_TRY(ws.h_rbox.reserve((g_r + 1) * 6 * 4));
+        LM_TRY(ws.h_pairs.reserve(g_p * 8));
+        LM_HIP(hipMemcpyAsync(const_cast<int*>(hs) + 3, pcount_dev, sizeof(unsigned), hipMemcpyDeviceToHost, side));
+        LM_HIP(hipMemcpyAsync(ws.h_rbox.p, ws.rbox.p, (g_r + 1) * 6 * 4, hipMemcpyDeviceToHost, side));
+        LM_HIP(hipMemcpyAsync(ws.h_pairs.p, ws.pairs.p, g_p * 8, hipMemcpyDeviceToHost, side));
+        return LM_OK;
+    };
     for (int attempt = 0;; ++attempt) {
         rcap = (int)std::min<size_t>((size_t)rcap, nvox);
         LM_TRY(ws.area.reserve(((size_t)rcap + 1) * 4));
         LM_TRY(ws.labval.reserve((size_t)rcap + 1));
         LM_TRY(ws.recs.reserve((size_t)cap * sizeof(BoundaryRec)));
+        const size_t g_r = tiny ? (size_t)std::min(rcap, 4) : (size_t)std::min(rcap, std::max(4096, ws.last_regions + ws.last_regions / 4 + 256));
+        if (side != s) {  // fork: the side stream sees the labelling, then works beside steps 2-3
+            LM_HIP(hipEventRecord(ws.side_fork, s));
+            LM_HIP(hipStreamWaitEvent(side, ws.side_fork, 0));
+            LM_TRY(enqueue_graph_inputs(g_r));
+            LM_HIP(hipEventRecord(ws.side_done, side));
+        }
         // ---- (2) regionprops: area + label value                                           utils.py:298
         LM_HIP(hipMemsetAsync(ws.area.p, 0, ((size_t)rcap + 1) * 4, s));
         LM_HIP(hipMemsetAsync(ws.labval.p, 0, (size_t)rcap + 1, s));
@@ -314,7 +349,6 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
             LM_K(boundary_records(ids, d, ws.recs.as<BoundaryRec>(), count_dev, cap, s));
         }
         // speculative read-back
-        const size_t g_r = tiny ? (size_t)std::min(rcap, 4) : (size_t)std::min(rcap, std::max(4096, ws.last_regions + ws.last_regions / 4 + 256));
         const size_t g_n = tiny ? std::min<size_t>(cap, 4) : std::min<size_t>(cap, std::max<size_t>(32768, (size_t)ws.last_records + ws.last_records / 4 + 1024));
         LM_TRY(ws.h_area.reserve((g_r + 1) * 4));
         LM_TRY(ws.h_labval.reserve(g_r + 1));
@@ -326,27 +360,11 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
         LM_HIP(hipMemcpyAsync(ws.h_recs.p, ws.recs.p, g_n * sizeof(BoundaryRec), hipMemcpyDeviceToHost, s));
         if (graph) {
             // The region-graph inputs of step 5 -- every region's bounding box and the pairs of regions that only touch diagonally --
-            // are not needed by the merge replay: their kernels and their read-back are enqueued BEHIND the first read-back, the host
-            // waits for an event between the two and replays the merge while they run.
+            // are not needed by the merge replay: the host waits for an event behind the FIRST read-back and replays the merge while
+            // they are still running (on the side stream; without one: behind the first read-back on this stream).
             if (!ws.tables_ready) LM_HIP(hipEventCreateWithFlags(&ws.tables_ready, hipEventDisableTiming));
             LM_HIP(hipEventRecord(ws.tables_ready, s));
-            LM_TRY(ws.rbox.reserve(((size_t)rcap + 1) * 6 * 4));
-            LM_TRY(ws.pairs.reserve((size_t)pcap * 8));
-            {
-                ProfScope ps(e, "post_region_boxes", (double)nvox * 4);
-                LM_K(region_stats_box(ids, lab, nullptr, nullptr, ws.rbox.as<int>(), d, s, rcap));
-            }
-            LM_HIP(hipMemsetAsync(pcount_dev, 0, sizeof(unsigned), s));
-            {
-                ProfScope ps(e, "post_diag_pairs", (double)nvox * 2);
-                LM_K(diag_pairs(lab, ids, d, ws.pairs.as<unsigned long long>(), pcount_dev, pcap, s));
-            }
-            g_p = tiny ? std::min<size_t>(pcap, 4) : std::min<size_t>(pcap, std::max<size_t>(16384, (size_t)ws.last_pairs + ws.last_pairs / 4 + 1024));
-            LM_TRY(ws.h_rbox.reserve((g_r + 1) * 6 * 4));
-            LM_TRY(ws.h_pairs.reserve(g_p * 8));
-            LM_HIP(hipMemcpyAsync(const_cast<int*>(hs) + 3, pcount_dev, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-            LM_HIP(hipMemcpyAsync(ws.h_rbox.p, ws.rbox.p, (g_r + 1) * 6 * 4, hipMemcpyDeviceToHost, s));
-            LM_HIP(hipMemcpyAsync(ws.h_pairs.p, ws.pairs.p, g_p * 8, hipMemcpyDeviceToHost, s));
+            if (side == s) LM_TRY(enqueue_graph_inputs(g_r));
         }
         t_enq1 = ms_now();
         if (graph) LM_HIP(hipEventSynchronize(ws.tables_ready));
@@ -361,7 +379,10 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
         if (R > rcap || nrec > cap) {  // rare: a table was too small -- grow and repeat the passes
             rcap = std::max(rcap, R);
             cap = std::max(cap, nrec);
-            if (graph) LM_HIP(hipStreamSynchronize(s));  // (the boxes / pairs kernels of this attempt write tables that are about to grow)
+            if (graph) {  // (the boxes / pairs kernels of this attempt write tables that are about to grow)
+                LM_HIP(hipStreamSynchronize(s));
+                if (side != s) LM_HIP(hipStreamSynchronize(side));
+            }
             continue;
         }
         if ((size_t)R > g_r || nrec > g_n) {  // the tables are complete on the device, the guess of what to fetch was short (first volume)
@@ -408,7 +429,8 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
         // ---- (5) on the region graph: kept component of every label, its bounding box; then per label the hole fill on its box
         static thread_local RegionGraph rg;
         rg.begin(R, lut, recs, nrec);     // (still beside the boxes / pairs kernels)
-        LM_HIP(hipStreamSynchronize(s));  // boxes + diagonal pairs
+        if (side != s) LM_HIP(hipEventSynchronize(ws.side_done));  // boxes + diagonal pairs
+        else LM_HIP(hipStreamSynchronize(s));
         npair = (unsigned)hs[3];
         while (npair > pcap) {  // rare: the pair table was too small -- grow it and repeat that one pass
             pcap = npair;
