@@ -111,3 +111,76 @@ def test_f16_range_guard_falls_back_to_exact_fp32(emu_engine, golden_dir):
     emu_engine.load_state_dict(0, uo.synthetic_state_dict(3))
     emu_engine.forward(0, x)
     assert emu_engine.model_precision(0) == "split_f16"
+
+
+def rescaled_batchnorm_state_dict(n_classes=3, seed=5):
+    """The synthetic network with every BatchNorm output channel multiplied by a factor f of either sign and up to 1.5 decades either
+    way (gamma and beta times f) and the consumers' input-channel weights divided by f: the SAME function, but BatchNorm scales like
+    a trained network may have them -- negative, tiny, large, wildly different within a layer.  The engine folds the scale into the
+    consumers' packed weights (LM_H3_FOLD_SCALE) with one power of two per layer: this is the case that would hurt it."""
+    import torch
+
+    sd = {k: v.clone() for k, v in uo.synthetic_state_dict(n_classes).items()}
+    g = torch.Generator().manual_seed(seed)
+
+    def factors(c):
+        f = torch.pow(10.0, torch.rand(c, generator=g) * 3.0 - 1.5) * torch.where(torch.rand(c, generator=g) < 0.3, -1.0, 1.0)
+        f[0], f[1] = -1.0, 1e-2  # (two fixed cases per layer)
+        return f
+
+    def scale_bn(prefix, f):
+        sd[prefix + ".weight"] = sd[prefix + ".weight"] * f
+        sd[prefix + ".bias"] = sd[prefix + ".bias"] * f
+
+    def unscale_consumer(conv, f, c0=0):
+        w = sd[conv + ".weight"]
+        w[:, c0 : c0 + len(f)] = w[:, c0 : c0 + len(f)] / f.view(1, -1, 1, 1)
+
+    for i in range(5):
+        c = 64 << i
+        p = f"down_path.{i}.block"
+        f = factors(c)
+        scale_bn(p + ".2", f)
+        unscale_consumer(p + ".3", f)
+        f = factors(c)
+        scale_bn(p + ".5", f)
+        if i < 4:
+            unscale_consumer(f"down_path.{i + 1}.block.0", f)                       # (through the average pool)
+            unscale_consumer(f"up_path.{3 - i}.conv_block.block.0", f, c0=c)       # the skip half of torch.cat([up, bridge], 1)
+        else:
+            unscale_consumer("up_path.0.up.1", f)                                   # (through the bilinear upsample)
+    for j in range(4):
+        c = 512 >> j
+        p = f"up_path.{j}.conv_block.block"
+        f = factors(c)
+        scale_bn(p + ".2", f)
+        unscale_consumer(p + ".3", f)
+        f = factors(c)
+        scale_bn(p + ".5", f)
+        unscale_consumer(f"up_path.{j + 1}.up.1" if j < 3 else "last", f)
+    return sd
+
+
+def check_rescaled_batchnorm(engine, x):
+    """engine(sd') against the oracle on sd' (and sd' computes what sd computes: the rescaling is function-preserving)."""
+    import torch
+
+    sd, sd2 = uo.synthetic_state_dict(3), rescaled_batchnorm_state_dict(3)
+    with torch.inference_mode():
+        ref = uo.forward(sd2, torch.from_numpy(x)).numpy()
+        same = uo.forward(sd, torch.from_numpy(x)).numpy()
+    assert np.abs(ref - same).max() < 2e-4  # (the construction is right: only fp32 rounding differs)
+    engine.load_state_dict(0, sd2)
+    lab, logp = engine.forward(0, x)
+    assert engine.model_precision(0) == "split_f16"  # (no range-guard fall-back: the stored tensors keep BatchNorm's magnitude)
+    err = np.abs(logp - ref).max()
+    assert err < TOL, err
+    srt = np.sort(ref, axis=1)
+    margin = srt[:, -1] - srt[:, -2]
+    assert not np.any((lab != ref.argmax(1)) & (margin > 2 * TOL))
+    return err
+
+
+def test_batchnorm_scales_of_any_sign_and_magnitude(emu_engine, golden_dir):
+    g = np.load(os.path.join(golden_dir, "unet_c3.npz"))
+    check_rescaled_batchnorm(emu_engine, g["rand32_x"][:1])

@@ -340,3 +340,14 @@ def test_f16_range_guard_falls_back_to_exact_fp32(gpu_engine):
     gpu_engine.load_state_dict(0, uo.synthetic_state_dict(3))
     gpu_engine.forward(0, x[:1])
     assert gpu_engine.model_precision(0) == "split_f16"
+
+
+def test_batchnorm_scales_of_any_sign_and_magnitude(gpu_engine, golden_dir):
+    """BatchNorm scales like a trained network may have them (negative, 1.5 decades either way within a layer) through the folded-scale
+    form of the conv path (nn_kernels.h: LM_H3_FOLD_SCALE): a function-preserving rescaling of the synthetic network, held to the
+    oracle on the same weights at 256 x 256 -- and no fall-back to the exact-fp32 kernels."""
+    from test_forward_emu import check_rescaled_batchnorm
+
+    g = np.load(os.path.join(golden_dir, "unet_c3.npz"))
+    err = check_rescaled_batchnorm(gpu_engine, g["phantom256_x"][:1])
+    print(f"rescaled BatchNorm: max|dlogp| = {err:.2e}")
