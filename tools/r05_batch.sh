@@ -1,6 +1,7 @@
 mkdir -p gpurun_out
-(LM_POST_SIDE=0 timeout 300 python tools/post_timing.py 2>&1 | grep -E "lm_postprocess|info" | tail -3; timeout 300 python tools/post_timing.py 2>&1 | grep -E "lm_postprocess|info" | tail -3) > gpurun_out/r05f_post_timing_side_stream.log; cat gpurun_out/r05f_post_timing_side_stream.log
-timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --host-steps 0 2>gpurun_out/r05f_bench_err.log | tail -1 > gpurun_out/r05f_bench.json; cut -c1-200 gpurun_out/r05f_bench.json
-LM_POST_SIDE=0 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --host-steps 0 2>>gpurun_out/r05f_bench_err.log | tail -1 > gpurun_out/r05f_bench_no_side.json; cut -c1-200 gpurun_out/r05f_bench_no_side.json
-timeout 900 python -m pytest tests/test_gpu_prepost.py tests/test_gpu_fullsize.py -m gpu -x -q -rs > gpurun_out/r05f_pytest_gpu.log 2>&1; grep -E "passed|failed|error" gpurun_out/r05f_pytest_gpu.log | tail -3
-timeout 300 python tools/stress.py 60 2>&1 | grep -v amdgpu.ids | tail -4
+for T in 0 200 400 1300 0 200; do
+  echo "== LM_H3_NT1_MAXITEMS=$T"
+  LM_H3_NT1_MAXITEMS=$T timeout 200 python tools/ab_forward.py lungmask_amd/liblungmask_hip.so 2>&1 | grep -v amdgpu.ids | grep "two lanes"
+  LM_H3_NT1_MAXITEMS=$T timeout 200 python tools/nn_perf.py 20 5 split_f16 2>&1 | grep -E "^B=|conv1x1"
+done > gpurun_out/r05g_nt1_ab.log 2>&1; cat gpurun_out/r05g_nt1_ab.log
+timeout 900 python -m pytest tests/test_gpu_forward.py -m gpu -x -q -rs > gpurun_out/r05g_pytest_gpu_forward.log 2>&1; grep -E "passed|failed|error" gpurun_out/r05g_pytest_gpu_forward.log | tail -2
