@@ -147,6 +147,20 @@ int lm_reorient_dev(lm_engine* e, const void* in_dev, void* out_dev, int elem_si
  * neighbours and dropped (fusion), may be NULL; skip_below: utils.py default 3. */
 int lm_postprocess_dev(lm_engine* e, uint8_t* lab_dev, int n, int h, int w, const int* spare, int n_spare,
                        int skip_below);
+/* ---- the two helpers of postprocessing as seams of their own (utils.py:361-387 bbox_3D, :390-404
+ *      keep_largest_connected_component; the reference's tests call bbox_3D directly, tests/test_utils.py:58-63) ---- */
+/* mask_dev u8 [n][h][w] (non-zero = set).  bbox_out (HOST, 6 ints) = [zmin, zmax, ymin, ymax, xmin, xmax]: first / last set index
+ * per axis, grown by `margin`, clipped to the volume, maxima exclusive (utils.py:376-383).  A mask without a set voxel has no
+ * box -- the reference raises IndexError at utils.py:377 -- and all six come back as -1.  Returns after the result is known. */
+int lm_bbox3d_dev(lm_engine* e, const uint8_t* mask_dev, int n, int h, int w, int margin, int32_t bbox_out[6]);
+/* mask_dev u8 [n][h][w], IN PLACE -> 1 on the voxels of the largest region of skimage.measure.label(mask) (full connectivity:
+ * 26 neighbours, 8 when n == 1; voxels of different non-zero values are different regions), 0 elsewhere.  Equal areas: the
+ * region whose first voxel (raster order) comes last -- what `np.argsort(resizes)[-1]` of utils.py:402 yields while numpy's sort
+ * is its stable insertion sort (<= 16 regions); beyond that the reference itself leaves the tie to numpy's quicksort.
+ * *area_out (HOST, may be NULL) = that region's voxel count; 0 = no region at all (the reference raises IndexError at
+ * utils.py:402), mask unchanged. */
+int lm_keep_largest_dev(lm_engine* e, uint8_t* mask_dev, int n, int h, int w, int64_t* area_out);
+
 /* What the last lm_postprocess_dev saw: info[0]=regions, [1]=boundary voxels shipped to the
  * host, [2]=regions processed by the merge loop, [3]=regions merged, [4]=host replay in us. */
 /* ---- the same post-processing with the volume's slices spread over `world` ranks (multi-GPU pipeline) ----

@@ -90,6 +90,8 @@ class Library:
         L.lm_reshape_mask_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
         L.lm_reorient_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_int64] * 4
         L.lm_postprocess_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]
+        L.lm_bbox3d_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]
+        L.lm_keep_largest_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]
         L.lm_slab_begin.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.POINTER(C.c_int), C.c_int, C.c_int]
         L.lm_slab_pending.argtypes = [C.c_void_p]
         L.lm_slab_pending.restype = C.c_int64
@@ -384,6 +386,34 @@ class Engine:
         out = ld.download()
         ld.free()
         return out
+
+    def bbox_3d(self, mask: np.ndarray, margin: int = 2):
+        """== utils.bbox_3D(labelmap, margin) for a [n, h, w] volume (non-zero = set): 6 ints, or None for an empty mask."""
+        md = self.to_device(np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8))
+        n, h, w = md.shape
+        bb = (C.c_int32 * 6)()
+        try:
+            self.L.check(self.L.lib.lm_bbox3d_dev(self.h, md.ptr, n, h, w, int(margin), bb), "lm_bbox3d_dev")
+        finally:
+            md.free()
+        return None if bb[1] < 0 else [int(v) for v in bb]
+
+    def keep_largest_dev(self, mask: DeviceArray) -> int:
+        n, h, w = mask.shape
+        area = C.c_int64()
+        self.L.check(self.L.lib.lm_keep_largest_dev(self.h, mask.ptr, n, h, w, C.byref(area)), "lm_keep_largest_dev")
+        return int(area.value)
+
+    def keep_largest(self, mask: np.ndarray):
+        """== utils.keep_largest_connected_component(mask) for a [n, h, w] u8 volume -> (bool volume, area); area 0 = no region."""
+        md = self.to_device(np.ascontiguousarray(mask, dtype=np.uint8))
+        try:
+            area = self.keep_largest_dev(md)
+            self.sync()
+            out = md.download()
+        finally:
+            md.free()
+        return out.astype(bool), area
 
     def postprocess_info(self) -> dict:
         buf = (C.c_int64 * 5)()

@@ -286,6 +286,27 @@ int lm_postprocess_dev(lm_engine* e, uint8_t* lab_dev, int n, int h, int w, cons
     return postprocess(e, lab_dev, n, h, w, spare, n_spare, skip_below);
 }
 
+int lm_bbox3d_dev(lm_engine* e, const uint8_t* mask_dev, int n, int h, int w, int margin, int32_t bbox_out[6]) {
+    if (!e || (!mask_dev && n > 0) || !bbox_out || n < 0 || h <= 0 || w <= 0 || margin < 0) {
+        set_error("lm_bbox3d_dev: bad arguments");
+        return LM_ERR_INVALID;
+    }
+    LM_DEVICE(e);
+    return bbox3d(e, mask_dev, n, h, w, margin, bbox_out);
+}
+
+int lm_keep_largest_dev(lm_engine* e, uint8_t* mask_dev, int n, int h, int w, int64_t* area_out) {
+    if (!e || (!mask_dev && n > 0) || n < 0 || h <= 0 || w <= 0) {
+        set_error("lm_keep_largest_dev: bad arguments");
+        return LM_ERR_INVALID;
+    }
+    LM_DEVICE(e);
+    long long a = 0;
+    const int rc = keep_largest(e, mask_dev, n, h, w, &a);
+    if (area_out) *area_out = (int64_t)a;
+    return rc;
+}
+
 int lm_slab_begin(lm_engine* e, uint8_t* lab_slab_dev, int n, int h, int w, int rank, int world, int z0, int n_total, const int* spare,
                   int n_spare, int skip_below) {
     if (!e || !lab_slab_dev || n_spare < 0) {

@@ -309,6 +309,9 @@ void replay_merge(int R, const int* area, const uint8_t* lv, const BoundaryRec* 
 int slab_begin(lm_engine* e, uint8_t* lab, int n, int h, int w, int rank, int world, int z0, int n_total, const int* spare, int n_spare, int skip_below);
 int slab_emit(lm_engine* e, int32_t* dst);
 int slab_step(lm_engine* e, const int32_t* gathered, long long stride, const long long* lens);
+// utils.py:361-387 / :390-404 as seams of their own (post_engine.hip)
+int bbox3d(lm_engine* e, const uint8_t* mask, int N, int H, int W, int margin, int32_t out[6]);
+int keep_largest(lm_engine* e, uint8_t* mask, int N, int H, int W, long long* area_out);
 int apply_volume(lm_engine* e, int slot, int fill_slot, const void* vol_dev, int dtype, int n, int h, int w, int batch_size,
                  int volume_postprocessing, uint8_t* out_dev);
 }  // namespace lm

@@ -574,6 +574,76 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
     return LM_OK;
 }
 
+// ------------------------------------------------------------------------------ utils.bbox_3D / keep_largest_connected_component
+// utils.py:361-387: per axis the first / last index with a non-zero voxel, grown by `margin` and clipped: [zmin, zmax, ymin, ymax,
+// xmin, xmax], maxima exclusive.  A mask without a non-zero voxel has no box (the reference raises IndexError at :377): all six -1.
+int bbox3d(lm_engine* e, const uint8_t* mask, int N, int H, int W, int margin, int32_t out[6]) {
+    for (int k = 0; k < 6; ++k) out[k] = -1;
+    if (N <= 0 || H <= 0 || W <= 0) return LM_OK;
+    const Dims d{N, H, W};
+    if (d.nvox() >= 0x7fffffffull) {
+        set_error("volume too large for 32-bit voxel indices");
+        return LM_ERR_INVALID;
+    }
+    PostWorkspace& ws = e->post;
+    LM_TRY(ws.scalars.reserve(4096));
+    int* box_dev = ws.scalars.as<int>() + 16;
+    {
+        ProfScope ps(e, "mask_bbox", (double)d.nvox());
+        LM_K(mask_bbox(mask, box_dev, d, e->stream));
+    }
+    int b[6];
+    LM_HIP(hipMemcpyAsync(b, box_dev, sizeof b, hipMemcpyDeviceToHost, e->stream));
+    LM_HIP(hipStreamSynchronize(e->stream));
+    if (b[3] < 0) return LM_OK;  // empty
+    const int dim[3] = {N, H, W};
+    for (int k = 0; k < 3; ++k) {
+        out[2 * k] = std::max(b[k] - margin, 0);                 // :378, :380
+        out[2 * k + 1] = std::min(b[3 + k] + margin + 1, dim[k]);  // :379, :381
+    }
+    return LM_OK;
+}
+
+// utils.py:390-404: skimage.measure.label (full connectivity; voxels of different non-zero values are different regions),
+// regionprops areas, `np.argsort(resizes)[-1] + 1`, `mask == max_region` -- in place, 0 / 1.  Equal areas: the reference leaves the
+// choice to numpy's argsort; up to 16 regions that is an insertion sort (stable), whose last element is the LAST of the equal
+// maxima -- regions are numbered by their first voxel in raster order, so that is the region whose first voxel comes last: the key
+// (area << 32 | root) of component_max, the same rule postprocess() applies.  *area_out = that region's area (0: no region at
+// all, the reference raises IndexError at :402; the mask is left untouched = all zero).
+int keep_largest(lm_engine* e, uint8_t* mask, int N, int H, int W, long long* area_out) {
+    if (area_out) *area_out = 0;
+    if (N <= 0 || H <= 0 || W <= 0) return LM_OK;
+    const Dims d{N, H, W};
+    const size_t nvox = d.nvox();
+    if (nvox >= 0x7fffffffull) {
+        set_error("volume too large for 32-bit voxel indices");
+        return LM_ERR_INVALID;
+    }
+    hipStream_t s = e->stream;
+    PostWorkspace& ws = e->post;
+    LM_TRY(ws.parent.reserve(nvox * 4));
+    LM_TRY(ws.ids.reserve(nvox * 4));
+    LM_TRY(ws.scalars.reserve(4096));
+    unsigned long long* best_dev = reinterpret_cast<unsigned long long*>(ws.scalars.as<char>() + 1024);
+    {
+        ProfScope ps(e, "post_ccl26_multilabel", (double)nvox * 13);
+        LM_K(ccl_label(mask, ws.parent.as<int>(), d, true, s));
+    }
+    {
+        ProfScope ps(e, "post_component_max", (double)nvox * 9);
+        LM_K(component_max(ws.parent.as<int>(), mask, ws.ids.as<int>(), best_dev, nvox, s));
+    }
+    unsigned long long best[256];
+    LM_HIP(hipMemcpyAsync(best, best_dev, sizeof best, hipMemcpyDeviceToHost, s));
+    LM_HIP(hipStreamSynchronize(s));
+    unsigned long long top = 0;
+    for (int label = 1; label < 256; ++label) top = std::max(top, best[label]);
+    if (!top) return LM_OK;
+    if (area_out) *area_out = (long long)(top >> 32);
+    LM_K(component_mask(ws.parent.as<int>(), (int)(unsigned)(top & 0xffffffffull), mask, nvox, s));
+    return LM_OK;
+}
+
 // ------------------------------------------------------------------------------ LMInferer.apply
 namespace {
 

@@ -106,6 +106,12 @@ hipError_t lut_complement(const int* ids, const uint8_t* keeplut, uint8_t label,
 hipError_t fill_write_lut(const int* ids2, const uint8_t* keeplut, const int* ids3, const uint8_t* holelut, uint8_t label, uint8_t* out,
                           size_t nvox, hipStream_t s);
 
+// ---- stand-alone seams of utils.bbox_3D (utils.py:361-387) and keep_largest_connected_component (utils.py:390-404)
+// box_dev[6] = {zmin, ymin, xmin, zmax, ymax, xmax} over the non-zero voxels of mask (INT_MAX / -1 when there is none)
+hipError_t mask_bbox(const uint8_t* mask, int* box_dev, Dims d, hipStream_t s);
+// out[v] = (parent[v] == keep_root)
+hipError_t component_mask(const int* parent, int keep_root, uint8_t* out, size_t nvox, hipStream_t s);
+
 // ---- fusion (mask.py:228-230)
 hipError_t volume_max(const uint8_t* a, unsigned* max_dev, size_t nvox, hipStream_t s);
 hipError_t fuse_labels(uint8_t* res_l, const uint8_t* res_r, uint8_t spare, size_t nvox, hipStream_t s);

@@ -758,6 +758,58 @@ __global__ __launch_bounds__(TPB) void volume_max_kernel(const uint8_t* __restri
     if (m) atomicMax(mx, m);
 }
 
+// ---- utils.bbox_3D (utils.py:361-387) and the last statement of keep_largest_connected_component (utils.py:403) as stand-alone seams
+// box[6] = {zmin, ymin, xmin, zmax, ymax, xmax} over the non-zero voxels (preset by the launcher: mins INT_MAX, maxs -1).  Eight voxels
+// per 64-bit load; coordinates are only worked out for words that hold a non-zero byte; one set of global atomics per workgroup, and
+// only where the (stale but monotone) value in memory does not already cover the workgroup's.
+__global__ __launch_bounds__(TPB) void mask_bbox_kernel(const uint8_t* __restrict__ m, int* box, Dims d) {
+    __shared__ int red[6][TPB / 64];
+    const size_t nvox = d.nvox();
+    int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
+    auto take = [&](size_t v) {
+        int x, y, z;
+        split3(v, d.H, d.W, x, y, z);
+        lo[0] = min(lo[0], z), lo[1] = min(lo[1], y), lo[2] = min(lo[2], x);
+        hi[0] = max(hi[0], z), hi[1] = max(hi[1], y), hi[2] = max(hi[2], x);
+    };
+    const size_t nword = ((reinterpret_cast<uintptr_t>(m) & 7) == 0) ? nvox / 8 : 0;
+    const unsigned long long* mw = reinterpret_cast<const unsigned long long*>(m);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nword; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned long long wv = mw[i];
+        if (!wv) continue;
+        for (int k = 0; k < 8; ++k)
+            if ((wv >> (8 * k)) & 0xffull) take(i * 8 + k);
+    }
+    for (size_t v = nword * 8 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x)
+        if (m[v]) take(v);
+    for (int k = 0; k < 3; ++k)
+        for (int off = 32; off; off >>= 1) {
+            lo[k] = min(lo[k], __shfl_xor(lo[k], off));
+            hi[k] = max(hi[k], __shfl_xor(hi[k], off));
+        }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+        for (int k = 0; k < 3; ++k) red[k][wave] = lo[k], red[3 + k][wave] = hi[k];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        int v = red[k][0];
+        for (int w2 = 1; w2 < TPB / 64; ++w2) v = k < 3 ? min(v, red[k][w2]) : max(v, red[k][w2]);
+        if (k < 3) {
+            if (v < *(volatile int*)&box[k]) atomicMin(&box[k], v);
+        } else if (v > *(volatile int*)&box[k]) atomicMax(&box[k], v);
+    }
+}
+
+__global__ __launch_bounds__(64) void mask_bbox_init_kernel(int* box) {
+    if (threadIdx.x < 6) box[threadIdx.x] = threadIdx.x < 3 ? 0x7fffffff : -1;
+}
+
+// out[v] = (parent[v] == keep_root): `mask == max_region` of utils.py:403
+__global__ __launch_bounds__(TPB) void component_mask_kernel(const int* __restrict__ P, int keep_root, uint8_t* __restrict__ out, size_t nvox) {
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x) out[v] = (P[v] == keep_root) ? 1 : 0;
+}
+
 __global__ __launch_bounds__(TPB) void fuse_kernel(uint8_t* res_l, const uint8_t* __restrict__ res_r, uint8_t spare, size_t nvox) {
     for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (size_t)gridDim.x * blockDim.x) {
         uint8_t l = res_l[v];
@@ -1212,6 +1264,17 @@ hipError_t volume_max(const uint8_t* a, unsigned* max_dev, size_t nvox, hipStrea
     hipError_t e = hipMemsetAsync(max_dev, 0, sizeof(unsigned), s);
     if (e != hipSuccess) return e;
     LM_LAUNCH(volume_max_kernel, dim3(grid_for(nvox)), dim3(TPB), 0, s, a, max_dev, nvox);
+    return hipGetLastError();
+}
+
+hipError_t mask_bbox(const uint8_t* mask, int* box_dev, Dims d, hipStream_t s) {
+    LM_LAUNCH(mask_bbox_init_kernel, dim3(1), dim3(64), 0, s, box_dev);
+    LM_LAUNCH(mask_bbox_kernel, dim3(grid_for(d.nvox(), TPB * 8 * 4, 2048)), dim3(TPB), 0, s, mask, box_dev, d);
+    return hipGetLastError();
+}
+
+hipError_t component_mask(const int* parent, int keep_root, uint8_t* out, size_t nvox, hipStream_t s) {
+    LM_LAUNCH(component_mask_kernel, dim3(grid_for(nvox)), dim3(TPB), 0, s, parent, keep_root, out, nvox);
     return hipGetLastError();
 }
 

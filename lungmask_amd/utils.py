@@ -6,10 +6,12 @@ conventions, executed by the MI355X engine (no CPU implementation here: every ca
     crop_and_resize       utils.py:85-111     lm_preprocess_dev on one slice
     reshape_mask          utils.py:114-129    lm_reshape_mask_dev
     postprocessing        utils.py:272-358    lm_postprocess_dev
+    bbox_3D               utils.py:361-387    lm_bbox3d_dev
+    keep_largest_connected_component  utils.py:390-404  lm_keep_largest_dev
     load_input_image / read_dicoms  utils.py:132-269   volume_io (host I/O)
 
-`bbox_3D` and `keep_largest_connected_component` (utils.py:361-404) are internal steps of `postprocessing` in the
-reference and live inside `lm_postprocess_dev` here; they are not exported on their own.
+`bbox_3D` and `keep_largest_connected_component` are steps of `postprocessing` in the reference (inside
+`lm_postprocess_dev` they run on the region graph); the two functions below are the same steps as calls of their own.
 
 The engine is created on first use (`set_engine` injects another one, e.g. a specific device)."""
 from __future__ import annotations
@@ -84,3 +86,39 @@ def postprocessing(label_image: np.ndarray, spare: Sequence[int] = (), disable_t
     lab = np.asarray(label_image)
     assert lab.ndim == 3, "postprocessing takes a [n, h, w] label volume"
     return _eng().postprocess(lab, spare=[int(s) for s in spare], skip_below=int(skip_below)).astype(lab.dtype, copy=False)
+
+
+def _as_3d(a: np.ndarray) -> np.ndarray:
+    if a.ndim < 1 or a.ndim > 3:
+        raise ValueError(f"the engine's volumes have 1 to 3 axes (got an array of shape {a.shape})")
+    return a.reshape((1,) * (3 - a.ndim) + a.shape)
+
+
+def bbox_3D(labelmap: np.ndarray, margin: int = 2) -> np.ndarray:
+    """utils.py:361-387: `[zmin, zmax, ymin, ymax, xmin, xmax]` (two entries per axis of `labelmap`, maxima exclusive) of the
+    non-zero voxels, grown by `margin` and clipped.  An all-zero labelmap raises IndexError, as the reference's
+    `np.where(margin_label)[0][[0, -1]]` does."""
+    lm_ = np.asarray(labelmap)
+    bb = _eng().bbox_3d(_as_3d(lm_), margin=int(margin))
+    if bb is None:
+        raise IndexError("bbox_3D of a labelmap without a non-zero voxel (utils.py:377)")
+    return np.asarray(bb[2 * (3 - lm_.ndim):], dtype=np.int64)
+
+
+def keep_largest_connected_component(mask: np.ndarray) -> np.ndarray:
+    """utils.py:390-404: bool mask of the largest region of `skimage.measure.label(mask)` (full connectivity; different non-zero
+    values are different regions).  Equal areas: the region whose first voxel comes last in raster order (what numpy's stable
+    insertion sort makes of `np.argsort(resizes)[-1]` up to 16 regions).  A mask without a region raises IndexError like :402."""
+    m = np.asarray(mask)
+    if m.dtype == bool:
+        m8 = m.astype(np.uint8)
+    elif m.dtype.kind in "iu" and m.size and 0 <= m.min() and m.max() <= 255:
+        m8 = m.astype(np.uint8)
+    elif m.size == 0:
+        m8 = m.astype(np.uint8)
+    else:
+        raise TypeError("keep_largest_connected_component on the engine takes bool masks or label maps with values in [0, 255]")
+    out, area = _eng().keep_largest(_as_3d(m8))
+    if area == 0:
+        raise IndexError("keep_largest_connected_component of a mask without a region (utils.py:402)")
+    return out.reshape(m.shape)

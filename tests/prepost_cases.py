@@ -290,3 +290,70 @@ def check_postprocess_diagonal_adversarial(eng, n_iter=60):
             out = eng.postprocess(lab, spare=list(spare), skip_below=skip)
             ref = po.postprocessing(lab.copy(), spare=list(spare), skip_below=skip)
             assert np.array_equal(out, ref), (it, shape, kind, spare, skip, int((out != ref).sum()))
+
+
+def check_bbox_klc(eng):
+    """utils.bbox_3D (utils.py:361-387) and utils.keep_largest_connected_component (utils.py:390-404) as calls of their own:
+    every `klc*` golden (outputs of the reference's own functions, oracle/_ref_runner.py), the reference's test vector
+    (tests/test_utils.py:58-63), differential cases against the oracle, the equal-area tie, the empty mask."""
+    from lungmask_amd import utils
+
+    utils.set_engine(eng)
+    try:
+        g = np.load(GOLD)
+        for i in range(int(g["n_klc"])):
+            m = g[f"klc{i}_mask"]
+            out = utils.keep_largest_connected_component(m)
+            assert out.dtype == bool and out.shape == m.shape
+            assert np.array_equal(np.packbits(out), g[f"klc{i}_out"]), i
+            bb = utils.bbox_3D(m)
+            assert np.array_equal(bb, g[f"klc{i}_bbox"]), (i, bb.tolist())
+        # tests/test_utils.py:58-63
+        m = np.zeros((10, 10, 10), dtype=np.uint8)
+        m[2:8, 3:7, 4:6] = 1
+        assert tuple(utils.bbox_3D(m, margin=2)) == (0, 10, 1, 9, 2, 8)
+        assert tuple(utils.bbox_3D(m, margin=0)) == (2, 8, 3, 7, 4, 6)
+        # differential: ragged shapes (rows that are no multiple of the 8-voxel words), label maps, 2-D masks
+        rng = np.random.default_rng(23)
+        for shape in ((5, 13, 11), (3, 32, 40), (1, 21, 19), (9, 7, 5)):
+            for p in (0.02, 0.3, 0.55):
+                m = rng.random(shape) < p
+                if not m.any():
+                    continue
+                for margin in (0, 2, 5):
+                    assert np.array_equal(utils.bbox_3D(m, margin=margin), po.bbox_3D(m, margin=margin)), (shape, p, margin)
+                ref = po.keep_largest_connected_component(m)
+                areas = np.bincount(po.sk_label(m).ravel())[1:]
+                if (areas == areas.max()).sum() == 1:  # (ties: below)
+                    assert np.array_equal(utils.keep_largest_connected_component(m), ref), (shape, p)
+            lab = rng.integers(0, 4, size=shape).astype(np.uint8)  # different non-zero values are different regions
+            areas = np.bincount(po.sk_label(lab).ravel())[1:]
+            if (areas == areas.max()).sum() == 1:
+                assert np.array_equal(utils.keep_largest_connected_component(lab), po.keep_largest_connected_component(lab)), shape
+        m2 = rng.random((17, 23)) < 0.4
+        assert np.array_equal(utils.bbox_3D(m2), po.bbox_3D(m2)) and utils.bbox_3D(m2).shape == (4,)
+        assert np.array_equal(utils.keep_largest_connected_component(m2), po.keep_largest_connected_component(m2))
+        # equal areas: the region whose first voxel comes LAST in raster order (the stable reading of np.argsort(...)[-1]; the
+        # reference leaves ties to numpy's unstable default sort) -- also across different label values
+        t = np.zeros((4, 12, 12), np.uint8)
+        t[0, 1:3, 1:3] = 1
+        t[2, 5:7, 5:7] = 1
+        t[3, 9:11, 1:3] = 1
+        want = np.zeros_like(t, bool)
+        want[3, 9:11, 1:3] = True
+        assert np.array_equal(utils.keep_largest_connected_component(t), want)
+        assert np.array_equal(po.keep_largest_connected_component(t), want)
+        t[3, 9:11, 1:3] = 0
+        t[1, 9:11, 9:11] = 2
+        want[:] = False
+        want[2, 5:7, 5:7] = True
+        assert np.array_equal(utils.keep_largest_connected_component(t), want)
+        # no region at all: IndexError, as utils.py:377 / :402
+        for fn in (utils.bbox_3D, utils.keep_largest_connected_component):
+            try:
+                fn(np.zeros((3, 8, 8), np.uint8))
+                raise AssertionError("an empty mask must raise IndexError like the reference")
+            except IndexError:
+                pass
+    finally:
+        utils.set_engine(None)

@@ -1,4 +1,4 @@
-"""The reference's own tests of the hot-path helpers (tests/test_utils.py:72-159 of JoHof/lungmask v0.2.20), restated
+"""The reference's own tests of the hot-path helpers (tests/test_utils.py:58-63 and :72-159 of JoHof/lungmask v0.2.20), restated
 against `lungmask_amd.utils` -- same inputs, same expected values."""
 import numpy as np
 
@@ -8,6 +8,11 @@ from lungmask_amd import utils
 def check_reference_utils_tests(engine):
     utils.set_engine(engine)
     try:
+        # test_bbox_3D (test_utils.py:58-63)
+        m = np.zeros((10, 10, 10), dtype=np.uint8)
+        m[2:8, 3:7, 4:6] = 1
+        bb = utils.bbox_3D(m, margin=2)
+        assert tuple(bb) == (0, 10, 1, 9, 2, 8)
         # test_simple_bodymask (test_utils.py:72-78)
         img = np.full((10, 10), dtype=np.int16, fill_value=-1000)
         img[2:8, 3:7] = 1

@@ -51,6 +51,24 @@ def test_empty_inputs(gpu_engine):
     assert gpu_engine.apply(0, np.zeros((0, 512, 512), np.int16)).shape == (0, 512, 512)
 
 
+def test_bbox_3d_and_keep_largest(gpu_engine):
+    """the reference-generated `klc*` goldens and tests/test_utils.py:58-63 through the HIP path."""
+    cases.check_bbox_klc(gpu_engine)
+    # a production-size mask: the phantom's lungs at 300 x 256 x 256 against the oracle
+    from lungmask_amd import utils
+
+    zz, yy, xx = np.ogrid[:300, :256, :256]
+    m = (((zz - 150) / 135.0) ** 2 + ((yy - 128) / 55.0) ** 2 + ((xx - 75) / 40.0) ** 2 < 1) | \
+        (((zz - 150) / 120.0) ** 2 + ((yy - 128) / 50.0) ** 2 + ((xx - 181) / 38.0) ** 2 < 1)
+    m[7, 3:5, 250:253] = True
+    utils.set_engine(gpu_engine)
+    try:
+        assert np.array_equal(utils.bbox_3D(m), po.bbox_3D(m))
+        assert np.array_equal(utils.keep_largest_connected_component(m), po.keep_largest_connected_component(m))
+    finally:
+        utils.set_engine(None)
+
+
 def test_reference_utils_tests(gpu_engine):
     """tests/test_utils.py of the reference, through the `lungmask_amd.utils` mirror."""
     from reference_utils_cases import check_reference_utils_tests

@@ -47,6 +47,10 @@ def test_reference_utils_tests_emulated(emu_engine):
     check_reference_utils_tests(emu_engine)
 
 
+def test_bbox_3d_and_keep_largest_emulated(emu_engine):
+    cases.check_bbox_klc(emu_engine)
+
+
 def test_fusion_emulated(emu_engine):
     cases.check_fuse(emu_engine)
 
