@@ -434,6 +434,16 @@ def main():
         fill_slot = 1
     eng.set_precision(args.precision)
     eng.set_streams(args.streams)
+    # what the load-time accuracy guard saw (include/lungmask_hip.h: lm_model_probe_error) and what the models therefore run on
+    guard = None
+    if hasattr(eng.L.lib, "lm_model_probe_error"):
+        guard = {"limit": os.environ.get("LM_ACC_GUARD", "5e-4 (default)"), "models": []}
+        for slot in ([0] if fill_slot < 0 else [0, 1]):
+            err, pinned = eng.model_probe(slot)
+            guard["models"].append({"slot": slot, "probe_max_abs_dlogp_split_vs_exact_fp32": err, "pinned_to_fp32_by_the_guard": pinned,
+                                    "runs_on": eng.model_precision(slot)})
+        guard["note"] = ("lm_model_load ran one deterministic 256 x 256 probe slice through the split-f16 and the exact-fp32 kernels of each model; a model "
+                         "above the limit is pinned to the exact kernels (the timed region below runs on whatever `runs_on` says)")
 
     n_local, n_total = args.slices, args.slices * world
     hw, res = ((96, 80), (32, 32)) if emu else ((512, 512), (256, 256))
@@ -540,6 +550,23 @@ def main():
         eng.set_streams(args.streams)
     if args.streams == 1:
         stats = stats or solo
+    # N > 1 (and the forced world of one): where ONE step's time goes on the engine's stream -- sliced stages, every collective with
+    # the bytes a rank contributes, post-processing, un-crop, output assembly -- and the host's share of the slab protocol; HIP events
+    # on the engine's stream, maximum over the ranks per entry (every rank walks the same sequence of stages and exchanges)
+    dist_breakdown = None
+    if use_dist:
+        pipe.want_breakdown = True
+        sync_all()
+        step()
+        sync_all()
+        bd = pipe.breakdown()
+        pipe.want_breakdown = False
+        if bd is not None:
+            dist_breakdown = {k: round(over_ranks(v), 4) for k, v in bd.items() if isinstance(v, float)}
+            dist_breakdown["collectives"] = [{"name": c["name"], "bytes_per_rank": c["bytes_per_rank"], "ms": round(over_ranks(c["ms"]), 4)} for c in bd["collectives"]]
+            dist_breakdown["note"] = ("one extra untimed step: HIP events on the engine's stream (the stream the kernels AND the collectives are enqueued on), max over "
+                                      "ranks per entry; *_ms = stream time of the stage without its collectives; host_merge_ms = wall time inside lm_slab_step "
+                                      "(the slab protocol's table merges incl. their waits for device data; 0 in the gathered form)")
 
     # numpy in -> numpy out: what a caller of the drop-in sees (SURVEY.md section 8d defines the metric on a host volume).  Two forms,
     # both over --steps steps like `value`, both reported beside `value`, never as `value` (the contract's timed region starts with
@@ -549,28 +576,63 @@ def main():
     host = lmi = None
     if not use_dist and args.host_steps > 0 and not emu:
         ref_labels = od.download()
+        n_rep = 1 + max(args.repeat, 0)
+
+        def timed_passes(fn):
+            """--host-steps calls of fn, 1 + --repeat times back to back (like the timed region): ms per call of every pass."""
+            out_ms = []
+            for _ in range(n_rep):
+                t0h = time.perf_counter()
+                for _ in range(args.host_steps):
+                    fn()
+                out_ms.append((time.perf_counter() - t0h) / args.host_steps * 1e3)
+            return out_ms
+
+        def leg(ms):
+            med = sorted(ms)[len(ms) // 2]
+            return {"value": round(n_total / med * 1e3, 2), "ms_per_step": round(med, 3),
+                    "passes_ms_per_step": [round(v, 3) for v in ms], "min": round(min(ms), 3), "median": round(med, 3), "max": round(max(ms), 3)}
+
         res_h = eng.apply(0, vol, fill_slot=fill_slot, batch_size=args.batch)
         eng.sync()
-        t0h = time.perf_counter()
-        for _ in range(args.host_steps):
-            eng.apply(0, vol, fill_slot=fill_slot, batch_size=args.batch, out=res_h)  # caller-owned output buffer, reused
-        dth = (time.perf_counter() - t0h) / args.host_steps
-        host = {"value": round(n_total / dth, 2), "unit": "slices/s", "ms_per_step": round(dth * 1e3, 3), "steps": args.host_steps,
-                "note": "numpy int16 volume in pageable host memory -> uint8 numpy labels in a caller-owned, reused host array (lm_apply_host), PCIe copies included; "
-                        "identical labels: " + str(bool(np.array_equal(res_h, ref_labels)))}
+        host = leg(timed_passes(lambda: eng.apply(0, vol, fill_slot=fill_slot, batch_size=args.batch, out=res_h)))  # caller-owned output buffer, reused
+        host.update({"unit": "slices/s", "steps": args.host_steps,
+                     "note": "numpy int16 volume in pageable host memory -> uint8 numpy labels in a caller-owned, reused host array (lm_apply_host), PCIe copies included; "
+                             f"`value` = the median of {n_rep} passes of --host-steps calls; identical labels: " + str(bool(np.array_equal(res_h, ref_labels)))})
         from lungmask_amd.mask import LMInferer
 
         lmi = {}
         for key, reuse in (("fresh_output_per_call", False), ("reuse_output", True)):
             inf = LMInferer(modelname="R231" if n_classes == 3 else "LTRCLobes", fillmodel="R231" if fill_classes else None, batch_size=args.batch,
                             device_id=local_rank, precision=args.precision, reuse_output=reuse, state_dict=sd, fill_state_dict=sd_fill, engine=eng)
-            r = inf.apply(vol)
-            r = inf.apply(vol)  # (steady state: the second result block of the pool exists before the clock starts)
-            t0h = time.perf_counter()
-            for _ in range(args.host_steps):
-                r = inf.apply(vol)
-            dth = (time.perf_counter() - t0h) / args.host_steps
-            lmi[key] = {"value": round(n_total / dth, 2), "ms_per_step": round(dth * 1e3, 3), "identical_labels": bool(np.array_equal(r, ref_labels))}
+            box = [inf.apply(vol)]
+            box[0] = inf.apply(vol)  # (steady state: the second result block of the pool exists before the clock starts)
+
+            def call(inf=inf, box=box):
+                box[0] = inf.apply(vol)
+
+            lmi[key] = leg(timed_passes(call))
+            lmi[key]["identical_labels"] = bool(np.array_equal(box[0], ref_labels))
+            if not reuse and hasattr(inf, "apply_async"):
+                # volumes queued through apply_async: the copy-back of volume i and the copy-in of volume i + 1 run beside the hot path
+                # of their neighbours (SURVEY 8f #4, "multi-volume queueing"); two volumes in flight, results consumed in order
+                def pipelined(inf=inf, box=box):
+                    pend = []
+                    for _ in range(args.host_steps):
+                        pend.append(inf.apply_async(vol))
+                        if len(pend) > 1:
+                            box[0] = pend.pop(0).result()
+                    while pend:
+                        box[0] = pend.pop(0).result()
+
+                ms = []
+                for _ in range(n_rep):
+                    t0h = time.perf_counter()
+                    pipelined()
+                    ms.append((time.perf_counter() - t0h) / args.host_steps * 1e3)
+                lmi["async_pipelined"] = leg(ms)
+                lmi["async_pipelined"]["identical_labels"] = bool(np.array_equal(box[0], ref_labels))
+            box[0] = None
         # the reference's cost model for comparison: a brand-new pageable numpy array per call (page faults + unmapping), results kept alive
         keep = []
         t0h = time.perf_counter()
@@ -580,7 +642,8 @@ def main():
         lmi["new_pageable_array_per_call"] = {"value": round(n_total / dth, 2), "ms_per_step": round(dth * 1e3, 3), "steps": len(keep)}
         del keep
         lmi.update({"unit": "slices/s", "steps": args.host_steps,
-                    "note": "lungmask_amd.LMInferer.apply(ndarray int16 [300,512,512]) -> ndarray uint8, the drop-in call itself (mask.py:212-232): "
+                    "note": f"every leg: `value` = the median of {n_rep} back-to-back passes of --host-steps calls (passes_ms_per_step).  "
+                            "lungmask_amd.LMInferer.apply(ndarray int16 [300,512,512]) -> ndarray uint8, the drop-in call itself (mask.py:212-232): "
                             "fresh_output_per_call = the reference's semantics, a result array of the caller's own per call -- a root array over a "
                             "page-locked block of the inferer's pool, given back by a finalizer when the result and all its views are gone (the loop "
                             "drops each result, so two blocks alternate); reuse_output = LMInferer(reuse_output=True), one pageable array for every "
@@ -671,6 +734,8 @@ def main():
                            "There is no first_conv / head_argmax row: the first conv runs inside the loader of down_path.0's second conv and the head "
                            "inside the last conv's epilogue (lm_set_fusion, default 11); both are part of conv3x3_igemm_h3",
             "postprocessing": post_info,
+            "dist_breakdown": dist_breakdown,
+            "accuracy_guard": guard,
         }
         if world == 1 and not args.no_cpu_baseline and not emu:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, sd)

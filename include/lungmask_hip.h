@@ -111,6 +111,14 @@ int lm_set_precision(lm_engine* e, int mode);
  * such range limit).  lm_forward_dev / lm_forward_batches_dev / lm_apply_* therefore return only after the forward has
  * finished. */
 int lm_model_precision(lm_engine* e, int slot);
+/* Accuracy guard.  lm_model_load on a split-f16 engine (and lm_set_precision(e, 1) for models loaded before it) runs ONE deterministic
+ * probe slice (256 x 256, phantom-like, in the network's [0, 1] input range) through the split-f16 and the exact-fp32 kernels of the
+ * model and pins it to the exact-fp32 kernels -- with a notice on stderr -- when max |delta log-prob| exceeds the limit (environment
+ * LM_ACC_GUARD, default 5e-4: half of the 1e-3 of the reference's fp32 result the engine is held to; "0" disables the probe).  A
+ * checkpoint with a logit range or weight tails beyond what the split arithmetic resolves therefore cannot silently sit outside the
+ * tolerance.  *err_out = the probe's max |delta log-prob| (< 0: no probe was run -- guard off, or the f16 range guard tripped on the
+ * probe and pinned the model first); returns 1 when the probe pinned the model, 0 when not, < 0 on error. */
+int lm_model_probe_error(lm_engine* e, int slot, float* err_out);
 
 /* ---- network forward (mask.py:178-186: model(mbt) + torch.max(pred,1)[1]) ------ */
 /* x_dev: f32 [b][h][w] (h, w multiples of 16).  labels_dev: u8 [b][h][w] or NULL.

@@ -81,6 +81,8 @@ class Library:
             L.lm_dist_destroy.argtypes = [C.c_void_p]
         if hasattr(L, "lm_model_precision"):  # (absent from older builds that tools/ab_forward.py may load for comparison)
             L.lm_model_precision.argtypes = [C.c_void_p, C.c_int]
+        if hasattr(L, "lm_model_probe_error"):
+            L.lm_model_probe_error.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
         L.lm_forward_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.lm_set_precision.argtypes = [C.c_void_p, C.c_int]
         L.lm_set_streams.argtypes = [C.c_void_p, C.c_int]
@@ -90,8 +92,9 @@ class Library:
         L.lm_reshape_mask_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
         L.lm_reorient_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_int64] * 4
         L.lm_postprocess_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]
-        L.lm_bbox3d_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]
-        L.lm_keep_largest_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]
+        if hasattr(L, "lm_bbox3d_dev"):  # (absent from older builds that tools/ab_forward.py may load for comparison)
+            L.lm_bbox3d_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]
+            L.lm_keep_largest_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]
         L.lm_slab_begin.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.POINTER(C.c_int), C.c_int, C.c_int]
         L.lm_slab_pending.argtypes = [C.c_void_p]
         L.lm_slab_pending.restype = C.c_int64
@@ -265,6 +268,13 @@ class Engine:
         return "split_f16" if self.L.check(self.L.lib.lm_model_precision(self.h, slot), "lm_model_precision") == 1 else "f32"
 
     # -- network
+    def model_probe(self, slot: int):
+        """(max |delta log-prob| split-f16 vs exact fp32 on the load-time probe slice or None when no probe ran, pinned by it?)"""
+        err = C.c_float()
+        rc = self.L.lib.lm_model_probe_error(self.h, slot, C.byref(err))
+        self.L.check(min(rc, 0), "lm_model_probe_error")
+        return (None if err.value < 0 else float(err.value)), rc == 1
+
     def set_precision(self, mode):
         """'f32' / 0: exact fp32 matrix ops;  'split_f16' / 1: 3-product split-f16."""
         m = {"f32": 0, "split_f16": 1}.get(mode, mode)

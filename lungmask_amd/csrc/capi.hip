@@ -149,7 +149,14 @@ int lm_copy_d2h(lm_engine* e, void* host_dst, const void* dev_src, size_t bytes)
 int lm_model_load(lm_engine* e, int slot, const lm_tensor* tensors, int n_tensors) {
     if (!e) return LM_ERR_INVALID;
     LM_HIP(hipSetDevice(e->device));
-    return model_load(e, slot, tensors, n_tensors);
+    LM_TRY(model_load(e, slot, tensors, n_tensors));
+    return model_probe(e, slot);  // accuracy guard (a split-f16 engine only)
+}
+
+int lm_model_probe_error(lm_engine* e, int slot, float* err_out) {
+    if (!e || slot < 0 || slot >= 4 || !e->models[slot].loaded || !err_out) return LM_ERR_NOMODEL;
+    *err_out = e->models[slot].probe_err;
+    return e->models[slot].acc_pinned ? 1 : 0;
 }
 void* lm_engine_stream(lm_engine* e) { return e ? reinterpret_cast<void*>(e->stream) : nullptr; }
 
@@ -169,6 +176,10 @@ int lm_set_precision(lm_engine* e, int mode) {
         return LM_ERR_INVALID;
     }
     e->precision = mode;
+    if (mode == 1) {  // models loaded while the engine was on the exact kernels have not met the accuracy guard yet
+        LM_DEVICE(e);
+        for (int slot = 0; slot < 4; ++slot) LM_TRY(model_probe(e, slot));
+    }
     return LM_OK;
 }
 

@@ -56,9 +56,9 @@ struct ConvLayer {
     // (1 top, 2 bottom, 4 left, 8 right) of S[tap][co] (zero padding pads the TRUE activation, not r).
     float *bias_h3 = nullptr, *corr_h3 = nullptr;
     std::vector<float> h_bn_t;  // host copy of this layer's own shift (empty: no BatchNorm)
-    // LM_H3_FOLD_SCALE: what a consumer multiplies this layer's stored channel by (s / 2^E; empty: 1) and the layer's 2^E
-    std::vector<float> h_fold_s;
-    float fold_pow2 = 1.f;
+    // LM_H3_FOLD_SCALE: this layer's BatchNorm scale s[co] = 2^e[co] * m[co]: h_row_pow2 = the 2^e[co] its own packed weight row and
+    // bias carry (exact), h_fold_s = the m[co] a consumer's weights carry for the stored channel (empty: 1)
+    std::vector<float> h_fold_s, h_row_pow2;
 };
 
 struct Model {
@@ -78,6 +78,9 @@ struct Model {
     // The split-f16 path stores activations as f16 pairs: a model whose activations left the f16 range (detected by the
     // kernels' range guard) is pinned to the exact-fp32 kernels from then on.
     bool force_f32 = false;
+    // accuracy guard (nn_engine.hip: model_probe): split-f16 against exact-fp32 on one probe slice at load time
+    bool probed = false, acc_pinned = false;
+    float probe_err = -1.f;  // max |delta log-prob| of the probe; < 0: not probed (guard off, fp32 engine, or the range guard tripped first)
     void release();
 };
 
@@ -296,6 +299,7 @@ int forward_batches(lm_engine* e, int slot, const float* x, int n, int H, int W,
 int forward_guarded(lm_engine* e, int slot, const float* x, int n, int H, int W, int batch, uint8_t* labels, float* logp);
 // the check alone, for callers that enqueue several forward_batches first (post_engine.hip: inference)
 int forward_range_check(lm_engine* e, int slot, bool* tripped);
+int model_probe(lm_engine* e, int slot);
 // range_slot >= 0: the f16 range flag of the forward that produced `lab` is read back in the SAME round trip as the region
 // count (instead of a synchronisation of its own before the call); when it is set, *range_tripped = true, the model of that
 // slot is pinned to the exact-fp32 kernels and nothing else is done (the caller repeats forward + post-processing).

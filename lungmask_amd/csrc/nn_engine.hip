@@ -63,6 +63,8 @@ void Model::release() {
     allocs.clear();
     loaded = false;
     force_f32 = false;
+    probed = acc_pinned = false;
+    probe_err = -1.f;
 }
 
 // ------------------------------------------------------------------------------ profiler
@@ -218,27 +220,44 @@ int load_conv(Model& md, const TensorMap& tm, const std::string& conv, const std
     const lm_tensor* w = tm.get(conv + ".weight", (int64_t)cout * cin * taps);
     const lm_tensor* b = tm.get(conv + ".bias", cout);
     if (!w || !b) return LM_ERR_INVALID;
-    // This layer's own BatchNorm scale, as its consumers will carry it (LM_H3_FOLD_SCALE): s[co] / 2^E with 2^E the power of two
-    // below the median |s| -- the stored tensor relu(.) * 2^E then has the magnitude BatchNorm would have given it.
-    float own_pow2 = 1.f;
+    // This layer's own BatchNorm scale s[co] = 2^e[co] * m[co], |m| in [1, 2) (LM_H3_FOLD_SCALE): the exact power of two goes into THIS
+    // layer's packed weight row and bias of output channel co -- relu(x) * 2^e == relu(x * 2^e), exact -- so that every stored
+    // channel keeps the magnitude BatchNorm would have given it (within a factor of two), and only the mantissa m[co] travels with
+    // the consumers' weights, whose dynamic range therefore stays that of w itself.  (Round 5 used ONE power of two per layer and
+    // folded s / 2^E into the consumers: a layer with BatchNorm scales spread over decades then had consumer rows spread over the
+    // same decades and stored near-dead channels as f16 subnormals.)  LM_H3_FOLD_PER_CHANNEL = 0 is that form, for A/B runs.
+    // The per-channel exponent is clamped to [-8, +4] around the layer's median exponent: a row that is scaled up sets the layer's
+    // shared 2^k and pushes the other rows' remainders towards the f16 subnormals, so an outlier beyond that keeps the rest of its
+    // scale in the consumers' factor instead.
+    std::vector<float> row_pow2(cout, 1.f);
     if (LM_H3_FOLD_SCALE && !bnp.empty()) {
         const lm_tensor* g = tm.get(bnp + ".weight", cout);
         const lm_tensor* var = tm.get(bnp + ".running_var", cout);
         if (!g || !var) return LM_ERR_INVALID;
-        std::vector<double> sd(cout), mag;
+        std::vector<double> sd(cout);
+        std::vector<int> ex(cout, 0), exs;
         for (int o = 0; o < cout; ++o) {
             sd[o] = (double)g->data[o] / std::sqrt((double)var->data[o] + 1e-5);
-            if (std::isfinite(sd[o]) && sd[o] != 0.0) mag.push_back(std::fabs(sd[o]));
+            if (std::isfinite(sd[o]) && sd[o] != 0.0) {
+                int e = 0;
+                (void)std::frexp(std::fabs(sd[o]), &e);  // |s| = f * 2^e, f in [0.5, 1)  ->  |s| = m * 2^(e - 1), m in [1, 2)
+                ex[o] = e - 1;
+                exs.push_back(e - 1);
+            }
         }
-        if (!mag.empty()) {
-            std::nth_element(mag.begin(), mag.begin() + mag.size() / 2, mag.end());
-            int e = 0;
-            (void)std::frexp(mag[mag.size() / 2], &e);  // median = m * 2^e, m in [0.5, 1)
-            own_pow2 = std::ldexp(1.f, std::min(std::max(e - 1, -60), 60));
+        int e_med = 0;
+        if (!exs.empty()) {
+            std::nth_element(exs.begin(), exs.begin() + exs.size() / 2, exs.end());
+            e_med = std::min(std::max(exs[exs.size() / 2], -60), 60);
         }
         L->h_fold_s.resize(cout);
-        for (int o = 0; o < cout; ++o) L->h_fold_s[o] = (float)(sd[o] / (double)own_pow2);
-        L->fold_pow2 = own_pow2;
+        for (int o = 0; o < cout; ++o) {
+            int e = e_med;
+            if (LM_H3_FOLD_PER_CHANNEL && std::isfinite(sd[o]) && sd[o] != 0.0) e = std::min(std::max(ex[o], e_med - 8), e_med + 4);
+            row_pow2[o] = std::ldexp(1.f, e);
+            L->h_fold_s[o] = (float)(sd[o] / (double)row_pow2[o]);
+        }
+        L->h_row_pow2 = row_pow2;
     }
     {
         // S[tap][co] = sum_ci w[co][ci][tap] * T[ci] in double; bias_h3 = bias + all taps; corr_h3[mask] = the taps that the
@@ -255,7 +274,7 @@ int load_conv(Model& md, const TensorMap& tm, const std::string& conv, const std
         for (int o = 0; o < cout; ++o) {
             double full = 0;
             for (int t = 0; t < taps; ++t) full += S[(size_t)t * cout + o];
-            be[o] = (float)(((double)b->data[o] + full) * (double)own_pow2);  // (own_pow2 == 1 without the fold)
+            be[o] = (float)(((double)b->data[o] + full) * (double)row_pow2[o]);  // (1 without the fold)
             if (taps == 9)
                 for (int mask = 1; mask < 16; ++mask) {
                     double c = 0;
@@ -263,7 +282,7 @@ int load_conv(Model& md, const TensorMap& tm, const std::string& conv, const std
                         const int dy = t / 3, dx = t % 3;
                         if (((mask & 1) && dy == 0) || ((mask & 2) && dy == 2) || ((mask & 4) && dx == 0) || ((mask & 8) && dx == 2)) c += S[(size_t)t * cout + o];
                     }
-                    corr[(size_t)mask * cout + o] = (float)(c * (double)own_pow2);
+                    corr[(size_t)mask * cout + o] = (float)(c * (double)row_pow2[o]);
                 }
         }
         LM_TRY(upload(md, be, &L->bias_h3));
@@ -280,9 +299,9 @@ int load_conv(Model& md, const TensorMap& tm, const std::string& conv, const std
         // weight down to 2^-14 of the largest one is a NORMAL f16 number (full 11-bit precision of lo -> 2^-22 relative on
         // w, also for heavy-tailed trained weights); 2^-k goes back in through the epilogue.
         const bool fold_in = LM_H3_FOLD_SCALE && s_in != nullptr && (int)s_in->size() == cin;
-        auto wf = [&](int o, int i, int t) -> float {  // the weight the matrix cores see: w * s_in[ci] (one rounding, from double)
+        auto wf = [&](int o, int i, int t) -> float {  // the weight the matrix cores see: w * s_in[ci] (one rounding, from double) * 2^e[co] (exact)
             const float v = w->data[((size_t)o * cin + i) * taps + t];
-            return fold_in ? (float)((double)v * (double)(*s_in)[i]) : v;
+            return (fold_in ? (float)((double)v * (double)(*s_in)[i]) : v) * row_pow2[o];
         };
         float wmax = 0.f;
         for (int o = 0; o < cout; ++o)
@@ -295,7 +314,7 @@ int load_conv(Model& md, const TensorMap& tm, const std::string& conv, const std
             k = 11 - e;                  // wmax * 2^k in [1024, 2048)
         }
         const float up = std::ldexp(1.f, k);
-        L->h3_acc_scale = std::ldexp(1.f, -k) * own_pow2;
+        L->h3_acc_scale = std::ldexp(1.f, -k);  // (the rows carry their own 2^e)
         std::vector<float> ph((size_t)taps * cout * cin);  // 4 bytes per element, viewed as halves below
         uint16_t* hp = reinterpret_cast<uint16_t*>(ph.data());
         for (int t = 0; t < taps; ++t)
@@ -407,16 +426,16 @@ int model_load(lm_engine* e, int slot, const lm_tensor* tensors, int n) {
         LM_TRY(upload(md, std::vector<float>(1024, 1.f), &md.ones_h3));
     }
     {   // the first conv as the split-f16 path wants it (ConvParamsH3::fc_c for the fused loader; first_conv_h3_kernel takes the same three
-        // arrays): w[9][64] | bias[64] | scale[64].  With LM_H3_FOLD_SCALE weights and bias are times the layer's 2^E (exact) and the
+        // arrays): w[9][64] | bias[64] | scale[64].  With LM_H3_FOLD_SCALE weights and bias are times the channel's 2^e (exact) and the
         // scale is 1: relu(x * 2^E) == relu(x) * 2^E, and the consumers carry s / 2^E.
         const lm_tensor* w = tm.get("down_path.0.block.0.weight", 64 * 9);
         const lm_tensor* b = tm.get("down_path.0.block.0.bias", 64);
         const lm_tensor* g = tm.get("down_path.0.block.2.weight", 64);
         const lm_tensor* var = tm.get("down_path.0.block.2.running_var", 64);
         if (!w || !b || !g || !var) return LM_ERR_INVALID;
-        const float e2 = LM_H3_FOLD_SCALE ? md.first.fold_pow2 : 1.f;
         std::vector<float> pk(9 * 64 + 128);
         for (int o = 0; o < 64; ++o) {
+            const float e2 = (LM_H3_FOLD_SCALE && !md.first.h_row_pow2.empty()) ? md.first.h_row_pow2[o] : 1.f;
             for (int t = 0; t < 9; ++t) pk[(size_t)t * 64 + o] = w->data[(size_t)o * 9 + t] * e2;
             pk[576 + o] = b->data[o] * e2;
             pk[640 + o] = LM_H3_FOLD_SCALE ? 1.f : (float)((double)g->data[o] / std::sqrt((double)var->data[o] + 1e-5));
@@ -570,6 +589,14 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
           e->prof.kind_id("first_conv"), e->prof.kind_id("upsample2x"), e->prof.kind_id("head_argmax"), h3};
     // LM_H3_DEFER_SHIFT=0: A/B hook (the tensors then hold the true activations, as in the exact-fp32 path)
     static const bool defer_ok = [] { const char* v = getenv("LM_H3_DEFER_SHIFT"); return !(v && v[0] == '0'); }();
+    if (LM_H3_FOLD_SCALE && !defer_ok) {
+        static const bool warned = [] {
+            fprintf(stderr, "lungmask_hip: LM_H3_DEFER_SHIFT=0 is ignored: this build folds the BatchNorm scale into the consumers (LM_H3_FOLD_SCALE), which "
+                            "presupposes the deferred shift; the non-deferred form needs a -DLM_H3_FOLD_SCALE=0 build (tools/build_variant.py)\n");
+            return true;
+        }();
+        (void)warned;
+    }
     f.defer = h3 && (defer_ok || LM_H3_FOLD_SCALE);  // (the folded scale presupposes the deferred shift)
     f.zeros = md.zeros_h3;
     f.ones = md.ones_h3;
@@ -702,6 +729,99 @@ int forward_batches(lm_engine* e, int slot, const float* x, int n, int H, int W,
     if (dual) {
         LM_HIP(hipEventRecord(e->ev_join, e->stream2));
         LM_HIP(hipStreamWaitEvent(e->stream, e->ev_join, 0));
+    }
+    return LM_OK;
+}
+
+// ------------------------------------------------------------------------------ accuracy guard
+// The split-f16 kernels carry every value to ~2^-22 and sum each output in ONE fp32 chain of 3 K / 16 roundings; how far that lands
+// from the reference's own fp32 arithmetic depends on the weights (logit range, heavy tails, K).  The range guard catches values that
+// leave f16; this guard catches a model whose split result is merely too far off: one deterministic probe slice (a phantom-like
+// body / lungs / noise image in the network's [0, 1] input range) goes through the split-f16 AND the exact-fp32 kernels on the
+// device, and when max |delta log-prob| exceeds the threshold (LM_ACC_GUARD, default 5e-4 -- half of the 1e-3 the engine is held
+// to; 0 disables) the model is pinned to the exact-fp32 kernels, with the same notice on stderr as the range guard's.
+namespace {
+void probe_image(int H, int W, std::vector<float>& x) {
+    x.resize((size_t)H * W);
+    uint32_t lcg = 0x2545f491u;
+    auto unit = [&] {  // uniform in [0, 1)
+        lcg = lcg * 1664525u + 1013904223u;
+        return (float)(lcg >> 8) * (1.f / 16777216.f);
+    };
+    const float cy = 0.5f * H, cx = 0.5f * W;
+    for (int y = 0; y < H; ++y)
+        for (int xx = 0; xx < W; ++xx) {
+            auto in = [&](float y0, float x0, float ry, float rx) {
+                const float dy = ((float)y - y0 * H) / (ry * H), dx = ((float)xx - x0 * W) / (rx * W);
+                return dy * dy + dx * dx < 1.f;
+            };
+            (void)cy, (void)cx;
+            float hu = -1000.f;
+            if (in(0.5f, 0.5f, 0.35f, 0.45f)) hu = (in(0.5f, 0.29f, 0.21f, 0.155f) || in(0.5f, 0.71f, 0.21f, 0.155f)) ? -850.f : 40.f;
+            hu += 20.f * 1.7320508f * ((unit() + unit() + unit() + unit()) - 2.f);  // ~N(0, 20)
+            hu = std::min(std::max(hu, -1024.f), 600.f);                            // mask.py:166-168
+            x[(size_t)y * W + xx] = (float)(((double)hu + 1024.0) / 1624.0);
+        }
+}
+}  // namespace
+
+int model_probe(lm_engine* e, int slot) {
+    Model& md = e->models[slot];
+    if (!md.loaded || md.probed || e->precision != 1) return LM_OK;
+    md.probed = true;
+    md.probe_err = -1.f;
+#ifdef LM_EMU_BUILD  // the test emulator probes only when asked to (every probe is two emulated forwards), and on a small image
+    static const char* const dflt = nullptr;
+    constexpr int HW = 32;
+#else
+    static const char* const dflt = "5e-4";
+    constexpr int HW = 256;
+#endif
+    const char* env = getenv("LM_ACC_GUARD");
+    if (!env) env = dflt;
+    const double thr = env ? atof(env) : 0.0;
+    if (!(thr > 0.0) || md.force_f32) return LM_OK;
+    std::vector<float> x;
+    probe_image(HW, HW, x);
+    const size_t nx = x.size(), nl = nx * md.n_classes;
+    DevBuf buf;
+    LM_TRY(buf.reserve((nx + 2 * nl) * sizeof(float) + nx));
+    float* xd = buf.as<float>();
+    float* lp[2] = {xd + nx, xd + nx + nl};
+    uint8_t* lab = reinterpret_cast<uint8_t*>(xd + nx + 2 * nl);  // (the production form of the last conv: head fused into its epilogue)
+    std::vector<float> h[2] = {std::vector<float>(nl), std::vector<float>(nl)};
+    auto fail = [&](int rc) { buf.release(); return rc; };
+    if (hipMemcpyAsync(xd, x.data(), nx * sizeof(float), hipMemcpyHostToDevice, e->stream) != hipSuccess) return fail(LM_ERR_DEVICE);
+    if (e->range_flag != nullptr && hipMemsetAsync(e->range_flag, 0, sizeof(unsigned), e->stream) != hipSuccess) return fail(LM_ERR_DEVICE);
+    const bool prof_on = e->prof.on;
+    e->prof.on = false;  // (the probe is not part of anybody's measurement)
+    int rc = forward(e, slot, xd, 1, HW, HW, lab, lp[0]);
+    bool tripped = false;
+    if (rc == LM_OK) rc = forward_range_check(e, slot, &tripped);  // (pins the model itself when the probe leaves the f16 range)
+    if (rc == LM_OK && !tripped) {
+        md.force_f32 = true;
+        rc = forward(e, slot, xd, 1, HW, HW, lab, lp[1]);
+        md.force_f32 = false;
+    }
+    e->prof.on = prof_on;
+    if (rc != LM_OK || tripped) return fail(rc);
+    for (int k = 0; k < 2; ++k)
+        if (hipMemcpyAsync(h[k].data(), lp[k], nl * sizeof(float), hipMemcpyDeviceToHost, e->stream) != hipSuccess) return fail(LM_ERR_DEVICE);
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(LM_ERR_DEVICE);
+    buf.release();
+    float err = 0.f;
+    for (size_t i = 0; i < nl; ++i) {
+        const float d = std::fabs(h[0][i] - h[1][i]);
+        err = (d > err || !(d == d)) ? (d == d ? d : INFINITY) : err;
+    }
+    md.probe_err = err;
+    if ((double)err > thr) {
+        md.force_f32 = true;
+        md.acc_pinned = true;
+        fprintf(stderr,
+                "lungmask_hip: model slot %d: the split-f16 kernels are %.2e from the exact-fp32 kernels on the probe slice (max |delta log-prob|, "
+                "limit %.1e): its forward passes run on the exact-fp32 matrix kernels (about 4x slower, same results as the reference)\n",
+                slot, (double)err, thr);
     }
     return LM_OK;
 }

@@ -105,13 +105,18 @@ struct ConvParamsH3 {
 int conv1x1_h3_ksplit(const ConvParamsH3& p);
 // whether launch_conv3x3_h3 can take the first layer into its loader for this shape (else run launch_first_conv_h3 first)
 bool conv3x3_h3_can_fuse_first(const ConvParamsH3& p);
-// LM_H3_FOLD_SCALE = 1: the BatchNorm SCALE of a Conv -> ReLU -> BN layer is folded into its consumers' packed weights the way its
-// shift already is (ConvLayer::bias_h3): the layer stores r' = relu(acc + b) * 2^E (E per layer, so that the tensor keeps the
-// magnitude BatchNorm gives it) and every consumer multiplies by w[co][ci] * s[ci] / 2^E -- average pool, bilinear upsample and concat
-// are per-channel linear, the sign of s is irrelevant.  One multiply per output less in every 3x3 epilogue and in the first-conv
-// producer, two LDS reads less per channel group; results differ from the unfolded form in the last bits only.
+// LM_H3_FOLD_SCALE = 1: the BatchNorm SCALE s = 2^e * m (|m| in [1, 2), per channel) of a Conv -> ReLU -> BN layer leaves the
+// epilogue: the exact power of two is folded into the layer's OWN packed weight row and bias (relu(x) 2^e == relu(x 2^e)), so the
+// layer stores r' = relu(acc + b) * 2^e[co] -- every channel at the magnitude BatchNorm gives it, within a factor of two -- and every
+// consumer multiplies by w[co][ci] * m[ci], the way it already carries the shift (ConvLayer::bias_h3); average pool, bilinear
+// upsample and concat are per-channel linear, the sign of s is irrelevant.  One multiply per output less in every 3x3 epilogue and in
+// the first-conv producer, two LDS reads less per channel group; results differ from the unfolded form in the last bits only.
 #ifndef LM_H3_FOLD_SCALE
 #define LM_H3_FOLD_SCALE 1  // (0: the scale applied in the producing epilogue, as in rounds 1-4 -- the A/B arm of profiles/r05a_*)
+#endif
+// 0: round 5's form -- ONE power of two per layer (below the median |s|), s / 2^E in the consumers (A/B arm of profiles/r06a_*)
+#ifndef LM_H3_FOLD_PER_CHANNEL
+#define LM_H3_FOLD_PER_CHANNEL 1
 #endif
 constexpr float kF16Guard = 32768.f;  // 2^15: a factor 2 below the largest finite half
 // whether launch_conv3x3_h3 can take the fused head for this shape (else run launch_head_h3 on the stored output)

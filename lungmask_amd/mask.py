@@ -65,10 +65,11 @@ class _ResultPool:
 
     @staticmethod
     def _host_free(L, engine_ref, addr):
-        eng = engine_ref()
-        h = getattr(eng, "h", None) if eng is not None else None
+        # Always with a NULL engine (allowed: include/lungmask_hip.h): this runs from finalizers, possibly on another thread, and an
+        # engine handle read here could be destroyed by a concurrent Engine.close() before lm_host_free synchronises its stream
+        # (ADVICE r05).  A page-locked block needs no stream sync to be freed: hipHostFree waits for the copies that use it.
         try:
-            L.lib.lm_host_free(h, ctypes.c_void_p(addr))  # (h == NULL is allowed: include/lungmask_hip.h)
+            L.lib.lm_host_free(None, ctypes.c_void_p(addr))
         except Exception:
             pass
 

@@ -138,6 +138,40 @@ class _InProcessMember:
         g.slots[self.rank] = None
 
 
+class _Marks:
+    """Time stamps on the engine's stream (HIP events through torch when the pipeline runs on a GPU, the host clock otherwise):
+    `mark(name)` closes the segment `name` -- everything enqueued on the stream since the previous mark."""
+
+    def __init__(self, stream, device):
+        self.stream, self.device = stream, device
+        self.names, self.events, self.extra = [], [], {}
+        self._stamp()
+
+    def _stamp(self):
+        if self.stream is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(self.stream)
+            self.events.append(ev)
+        else:
+            import time
+
+            self.events.append(time.perf_counter())
+
+    def mark(self, name: str):
+        self.names.append(name)
+        self._stamp()
+
+    def add(self, key: str, ms: float):
+        self.extra[key] = self.extra.get(key, 0.0) + ms
+
+    def segments(self):
+        """[(name, ms)] in stream order (waits for the stream)."""
+        if self.stream is not None:
+            self.events[-1].synchronize()
+            return [(n, float(self.events[i].elapsed_time(self.events[i + 1]))) for i, n in enumerate(self.names)]
+        return [(n, (self.events[i + 1] - self.events[i]) * 1e3) for i, n in enumerate(self.names)]
+
+
 class ShardedPipeline:
     """engine: lungmask_amd._native.Engine; dist: the torch.distributed module (initialised), a NativeDist, an InProcessGroup
     member, or None; device: torch device that matches the engine's memory space ('cuda:<i>' or 'cpu' under emulation);
@@ -166,6 +200,11 @@ class ShardedPipeline:
         self._slab_caps = {}   # agreed capacity (ints) of the variable-length table exchange of every protocol round, per volume geometry
         self._slab_key = None
         self.collectives = 0   # collectives issued for variable-length tables (tests / tools/slab_timing.py read it)
+        # breakdown of ONE call (bench.py's N > 1 line; `want_breakdown = True` before apply_shard, `breakdown()` after): where the
+        # step's time goes on the engine's stream -- sliced stages, every collective with its bytes, post-processing, un-crop --
+        # and how long the host sat in the slab protocol's table merges
+        self.want_breakdown = False
+        self._marks = None
         # the engine's stream as torch's current stream (see the module docstring); None on the CPU / under emulation
         self._stream = None
         if self.device.type == "cuda" and engine.stream_handle():
@@ -188,12 +227,44 @@ class ShardedPipeline:
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
 
-    def _all_gather(self, out: torch.Tensor, mine: torch.Tensor):
+    def _all_gather(self, out: torch.Tensor, mine: torch.Tensor, name: str = "tables"):
         # gloo must not alias input and output; RCCL gathers in place.  Called with the engine's stream current: no host
         # synchronisation here (without that stream, e.g. an engine of another build, fall back to a device sync)
+        if self._marks is not None:
+            self._marks.mark("compute")  # (whatever ran on the stream since the last mark; breakdown() sorts it into stages)
         self.dist.all_gather_into_tensor(out, mine.clone() if self.device.type == "cpu" else mine)
         if self._stream is None:
             self._sync_torch()
+        if self._marks is not None:
+            self._marks.mark(f"collective:{name}:{mine.numel() * mine.element_size()}")
+
+    def _stage(self, name: str):
+        if self._marks is not None:
+            self._marks.mark("stage:" + name)
+
+    def breakdown(self):
+        """The call's time line as bench.py reports it (dist_breakdown), or None when `want_breakdown` was off.  Stream time between
+        two marks belongs to the stage that closes the run of segments (`stage:` marks); collectives are listed one by one with
+        the bytes this rank contributed; host_merge_ms = wall time the host spent inside lm_slab_step (table merges + the waits
+        for the device data they need)."""
+        m = self._marks
+        if m is None:
+            return None
+        stages, coll, pend = {}, [], 0.0
+        for name, ms in m.segments():
+            if name.startswith("collective:"):
+                _, what, nbytes = name.split(":")
+                coll.append({"name": what, "bytes_per_rank": int(nbytes), "ms": round(ms, 4)})
+            elif name.startswith("stage:"):
+                stages[name[6:]] = round(stages.get(name[6:], 0.0) + pend + ms, 4)
+                pend = 0.0
+            else:
+                pend += ms
+        out = {k + "_ms": v for k, v in stages.items()}
+        out["host_merge_ms"] = round(m.extra.get("host_merge", 0.0), 4)
+        out["collectives"] = coll
+        out["collectives_ms"] = round(sum(c["ms"] for c in coll), 4)
+        return out
 
     def postprocess_slab(self, lab_slab: torch.Tensor, z0: int, n_total: int, spare: Sequence[int] = (), skip_below: int = 3):
         """utils.postprocessing over a volume whose slices are spread over the ranks; `lab_slab` (uint8 [n_r,h,w], n_r >= 1,
@@ -227,7 +298,7 @@ class ShardedPipeline:
                 gathered = self._tensor("slab_all", (self.world * max(stride, 1),), torch.int32)
                 e.L.check(lib.lm_slab_emit(e.h, mine.data_ptr()), "lm_slab_emit")
                 if stride:
-                    self._all_gather(gathered, mine)
+                    self._all_gather(gathered, mine, f"slab_planes_round{rnd}")
             else:
                 # variable-length tables: every rank sends [length | table | padding] of ONE agreed size, so the lengths travel
                 # inside the table exchange (6 collectives per volume instead of 9).  The agreed capacity of round `rnd` is what
@@ -242,7 +313,7 @@ class ShardedPipeline:
                     mine[:1].fill_(n)
                     if n <= cap:
                         e.L.check(lib.lm_slab_emit(e.h, mine.data_ptr() + 4), "lm_slab_emit")
-                    self._all_gather(gathered, mine)
+                    self._all_gather(gathered, mine, f"slab_table_round{rnd}")
                     self.collectives += 1
                     got = [int(v) for v in gathered.view(self.world, cap + 1)[:, 0].cpu().tolist()]
                     if max(got) <= cap:
@@ -252,7 +323,7 @@ class ShardedPipeline:
                 if lens is None:
                     if lens_known is None:
                         lens_t = self._tensor("slab_lens", (self.world,), torch.int64)
-                        self._all_gather(lens_t, torch.tensor([n], dtype=torch.int64, device=self.device))
+                        self._all_gather(lens_t, torch.tensor([n], dtype=torch.int64, device=self.device), f"slab_lengths_round{rnd}")
                         lens_known = [int(v) for v in lens_t.cpu().tolist()]
                         self.collectives += 1
                     lens, stride = lens_known, max(lens_known)
@@ -260,11 +331,17 @@ class ShardedPipeline:
                     gathered = self._tensor("slab_all", (self.world * max(stride, 1),), torch.int32)
                     e.L.check(lib.lm_slab_emit(e.h, mine.data_ptr()), "lm_slab_emit")
                     if stride:
-                        self._all_gather(gathered, mine)
+                        self._all_gather(gathered, mine, f"slab_table_round{rnd}")
                         self.collectives += 1
                 # (monotone: alternating small and large volumes must not fall back to the exact-size exchange every other time)
                 self._slab_caps[(self._slab_key, rnd)] = max(self._slab_caps.get((self._slab_key, rnd), 0), -(-(max(lens) + max(lens) // 4 + 256) // 1024) * 1024)
+            if self._marks is not None:
+                import time
+
+                t0 = time.perf_counter()
             status = e.L.check(lib.lm_slab_step(e.h, gathered.data_ptr() + 4 * hdr, stride, (C.c_int64 * self.world)(*lens)), "lm_slab_step")
+            if self._marks is not None:
+                self._marks.add("host_merge", (time.perf_counter() - t0) * 1e3)
             rnd += 1
             if status == 1:
                 return
@@ -336,6 +413,7 @@ class ShardedPipeline:
             self._stream.wait_event(ev)
         else:
             self._sync_torch()
+        self._marks = _Marks(self._stream, self.device) if self.want_breakdown else None
         # ---- sliced stages: no communication
         if n_r:
             e.L.check(lib.lm_preprocess_dev(e.h, vol_shard.data_ptr(), dtype, n_r, h, w, oh, ow, bbox.data_ptr(), xf.data_ptr(), None, None), "lm_preprocess_dev")
@@ -343,6 +421,7 @@ class ShardedPipeline:
         if self.fill_slot < 0:
             if self._stream is None:
                 e.sync()
+            self._stage("forward")
             return self.assemble(n_total, h, w, gather=gather)
         # ---- fused mode: the fill model on the same pre-processed slices (the reference recomputes the identical pre-processing)
         _, _, _, lab_fill = self.shard_buffers(n_total, "lab_fill")
@@ -350,6 +429,7 @@ class ShardedPipeline:
             e.L.check(lib.lm_forward_batches_dev(e.h, self.fill_slot, xf.data_ptr(), n_r, oh, ow, self.batch_size, lab_fill.data_ptr()), "lm_forward_batches_dev")
         if self._stream is None:
             e.sync()
+        self._stage("forward")
         return self.assemble_fused(n_total, h, w, gather=gather)
 
     def assemble(self, n_total: int, h: int, w: int, gather: bool = True) -> torch.Tensor:
@@ -403,7 +483,7 @@ class ShardedPipeline:
         # ---- exchange #1: 256^2 label shards -> whole label volume on every rank (RCCL all-gather, in place)
         if self.dist is not None:
             if self.volume_postprocessing:  # (without the volume pass every rank only needs its own slices)
-                self._all_gather(lab_all.view(-1), lab_loc.reshape(-1))
+                self._all_gather(lab_all.view(-1), lab_loc.reshape(-1), "label_shards")
                 full = self._compact(lab_all, counts, maxc)
             else:
                 return lab_loc[:n_r]
@@ -429,17 +509,21 @@ class ShardedPipeline:
         if not gather:
             return out_loc[:n_r]
         if self.dist is not None:
-            self._all_gather(out_all.view(-1), out_loc.reshape(-1))
-            return self._compact(out_all, counts, maxc)
+            self._all_gather(out_all.view(-1), out_loc.reshape(-1), "output_shards")
+            res = self._compact(out_all, counts, maxc)
+            self._stage("output_assembly")
+            return res
         return out_all[:n_r]
 
     def _assemble(self, n_total: int, h: int, w: int, gather: bool = True) -> torch.Tensor:
         _, counts = self._counts(n_total)
         n_r, maxc = counts[self.rank], max(counts)
         mine_lab = self._post_lowres(n_total, "lab_all")
+        self._stage("post")
         # ---- un-crop own slices
         out_all = self._tensor("out_all", (self.world * maxc, h, w), torch.uint8)
         self._uncrop(mine_lab, out_all[self.rank * maxc : (self.rank + 1) * maxc], n_r, h, w)
+        self._stage("uncrop")
         # ---- exchange #2: output shards
         return self._gather_out(out_all, counts, gather)
 
@@ -454,6 +538,7 @@ class ShardedPipeline:
         res_r = self._tensor("res_r", (max(n_r, 1), h, w), torch.uint8)
         self._uncrop(self._post_lowres(n_total, "lab_all"), out_loc, n_r, h, w)   # res_l (mask.py:222)
         self._uncrop(self._post_lowres(n_total, "lab_fill"), res_r, n_r, h, w)     # res_r (mask.py:227)
+        self._stage("post")
         # ---- spare = res_l.max() + 1 over the whole volume (mask.py:228): every rank's maximum, one 4-byte all-gather
         mx = C.c_int(0)
         e.L.check(lib.lm_label_max_dev(e.h, out_loc.data_ptr(), n_r * h * w, C.byref(mx)), "lm_label_max_dev")
@@ -462,16 +547,18 @@ class ShardedPipeline:
             mine = self._tensor("mx_mine", (1,), torch.int32)
             mx_all = self._tensor("mx_all", (self.world,), torch.int32)
             mine.fill_(top)
-            self._all_gather(mx_all, mine)
+            self._all_gather(mx_all, mine, "spare_label_max")
             top = max(int(v) for v in mx_all.cpu().tolist())
         spare = (top + 1) & 0xff  # uint8 arithmetic, as the reference's numpy expression
         e.L.check(lib.lm_fuse_spare_dev(e.h, out_loc.data_ptr(), res_r.data_ptr(), n_r * h * w, spare), "lm_fuse_spare_dev")  # mask.py:229-230
         # ---- postprocessing(res_l, spare=[spare]) at full resolution (mask.py:232; not conditional on volume_postprocessing)
+        self._stage("fusion")
         if self._use_slabs(counts, n_total):
             self.postprocess_slab(out_loc[:n_r], bounds[self.rank], n_total, spare=(spare,))
+            self._stage("post_fullres")
             return self._gather_out(out_all, counts, gather)
         if self.dist is not None:
-            self._all_gather(out_all.view(-1), out_loc.reshape(-1))
+            self._all_gather(out_all.view(-1), out_loc.reshape(-1), "fused_slabs")
             full = self._compact(out_all, counts, maxc)
         else:
             full = out_all[:n_r]
@@ -482,6 +569,7 @@ class ShardedPipeline:
             e.L.check(lib.lm_postprocess_dev(e.h, full.data_ptr(), n_total, h, w, sp, 1, 3), "lm_postprocess_dev")
         if self._stream is None:
             e.sync()
+        self._stage("post_fullres")
         # every rank now holds the complete result: no output collective in this form
         return full if gather else full[bounds[self.rank] : bounds[self.rank + 1]]
 

@@ -53,6 +53,12 @@ def _check_line(r, n_local, repeat=0):
     rep = out["repetitions"]
     assert len(rep["ms_per_step"]) == 1 + repeat and rep["ms_per_step"][0] == out["ms_per_step"] and rep["min"] <= rep["median"] <= rep["max"]
     assert out["chip_during_timed_region"] is None  # (no chip to sample under emulation)
+    # the N > 1 line explains itself: stages, every collective with its bytes, the host's share of the slab protocol
+    bd = out["dist_breakdown"]
+    assert bd["forward_ms"] > 0 and bd["post_ms"] >= 0 and bd["uncrop_ms"] >= 0 and "host_merge_ms" in bd
+    names = [c["name"] for c in bd["collectives"]]
+    assert names[0] == "label_shards" and names[-1] == "output_shards" and all(c["bytes_per_rank"] > 0 and c["ms"] >= 0 for c in bd["collectives"])
+    assert abs(bd["collectives_ms"] - sum(c["ms"] for c in bd["collectives"])) < 1e-2
 
 
 def test_self_spawned_two_ranks_over_gloo_and_the_emulator():

@@ -184,3 +184,60 @@ def check_rescaled_batchnorm(engine, x):
 def test_batchnorm_scales_of_any_sign_and_magnitude(emu_engine, golden_dir):
     g = np.load(os.path.join(golden_dir, "unet_c3.npz"))
     check_rescaled_batchnorm(emu_engine, g["rand32_x"][:1])
+
+
+def test_accuracy_guard_pins_a_model_the_split_kernels_cannot_resolve(emu_engine, golden_dir, monkeypatch):
+    """The load-time accuracy guard (nn_engine.hip: model_probe; on in the product build, opt-in on the emulator where a probe is two
+    emulated forwards): the Appendix-D model passes and stays on the split-f16 kernels; the same network with a head calibrated to a
+    logit standard deviation of 30 is further than 5e-4 from the exact-fp32 kernels on the probe slice, gets pinned to them at load
+    -- with a notice, like the range guard's -- and its result meets the 1e-3 bar."""
+    import torch
+
+    g = np.load(os.path.join(golden_dir, "unet_c3.npz"))
+    x = g["rand32_x"][:1]
+    base = uo.synthetic_state_dict(3)
+    monkeypatch.setenv("LM_ACC_GUARD", "5e-4")
+    try:
+        emu_engine.set_precision("split_f16")
+        emu_engine.load_state_dict(0, base)
+        err, pinned = emu_engine.model_probe(0)
+        assert err is not None and 0 < err < 5e-4 and not pinned and emu_engine.model_precision(0) == "split_f16"
+        sd = uo.calibrate_head(base, torch.from_numpy(x), 30.0)
+        emu_engine.load_state_dict(0, sd)
+        err, pinned = emu_engine.model_probe(0)
+        assert err is not None and err > 5e-4 and pinned and emu_engine.model_precision(0) == "f32"
+        with torch.inference_mode():
+            ref = uo.forward(sd, torch.from_numpy(x)).numpy()
+        lab, logp = emu_engine.forward(0, x)
+        assert np.abs(logp - ref).max() < TOL
+        # the guard is per loaded model; "0" switches it off
+        monkeypatch.setenv("LM_ACC_GUARD", "0")
+        emu_engine.load_state_dict(0, sd)
+        assert emu_engine.model_probe(0) == (None, False) and emu_engine.model_precision(0) == "split_f16"
+    finally:
+        monkeypatch.delenv("LM_ACC_GUARD", raising=False)
+        emu_engine.load_state_dict(0, base)
+
+
+def wide_batchnorm_heavy_tail_state_dict(n_classes=3, seed=9, decades=3.0, outlier=60.0, frac=5e-4):
+    """BatchNorm scales spread over `decades` decades within every layer (gamma and beta times f; NOT compensated in the consumers: a
+    different network, with channels that really are 30x louder or quieter than their neighbours, and a few near-dead ones at 1e-4)
+    AND conv weights with `outlier`-fold outliers -- the two things a trained checkpoint can have that the seeded stand-in does
+    not.  Both sides (oracle and engine) get the same tensors."""
+    import torch
+
+    sd = {k: v.clone() for k, v in uo.synthetic_state_dict(n_classes).items()}
+    g = torch.Generator().manual_seed(seed)
+    for k in list(sd):
+        v = sd[k]
+        if k.endswith(".weight") and v.ndim == 1 and (".block.2." in k or ".block.5." in k):  # BatchNorm gamma (and its beta)
+            c = v.shape[0]
+            f = torch.pow(10.0, (torch.rand(c, generator=g) - 0.5) * decades) * torch.where(torch.rand(c, generator=g) < 0.3, -1.0, 1.0)
+            f = f / f.abs().pow(2).mean().sqrt()  # (keep the layer's output power: the activations stay in the stand-in's range)
+            f[0], f[1] = 1e-4, -1e-4              # near-dead channels
+            sd[k] = v * f
+            sd[k[:-6] + "bias"] = sd[k[:-6] + "bias"] * f
+        elif k.endswith(".weight") and v.ndim == 4 and v.shape[-1] == 3 and v.shape[1] >= 64:
+            mask = torch.rand(v.shape, generator=g) < frac
+            sd[k] = torch.where(mask, v * outlier, v)
+    return sd
