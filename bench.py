@@ -442,7 +442,7 @@ def main():
             err, pinned = eng.model_probe(slot)
             guard["models"].append({"slot": slot, "probe_max_abs_dlogp_split_vs_exact_fp32": err, "pinned_to_fp32_by_the_guard": pinned,
                                     "runs_on": eng.model_precision(slot)})
-        guard["note"] = ("lm_model_load ran one deterministic 256 x 256 probe slice through the split-f16 and the exact-fp32 kernels of each model; a model "
+        guard["note"] = ("lm_model_load ran two deterministic 256 x 256 probe slices (phantom-like, uniform noise) through the split-f16 and the exact-fp32 kernels of each model; a model "
                          "above the limit is pinned to the exact kernels (the timed region below runs on whatever `runs_on` says)")
 
     n_local, n_total = args.slices, args.slices * world
@@ -564,6 +564,7 @@ def main():
         if bd is not None:
             dist_breakdown = {k: round(over_ranks(v), 4) for k, v in bd.items() if isinstance(v, float)}
             dist_breakdown["collectives"] = [{"name": c["name"], "bytes_per_rank": c["bytes_per_rank"], "ms": round(over_ranks(c["ms"]), 4)} for c in bd["collectives"]]
+            dist_breakdown["segments_rank0"] = bd.get("segments")
             dist_breakdown["note"] = ("one extra untimed step: HIP events on the engine's stream (the stream the kernels AND the collectives are enqueued on), max over "
                                       "ranks per entry; *_ms = stream time of the stage without its collectives; host_merge_ms = wall time inside lm_slab_step "
                                       "(the slab protocol's table merges incl. their waits for device data; 0 in the gathered form)")
@@ -616,22 +617,24 @@ def main():
             if not reuse and hasattr(inf, "apply_async"):
                 # volumes queued through apply_async: the copy-back of volume i and the copy-in of volume i + 1 run beside the hot path
                 # of their neighbours ("multi-volume queueing"); two volumes in flight, results consumed in order
-                def pipelined(inf=inf, box=box):
-                    pend = []
-                    for _ in range(args.host_steps):
+                # ONE continuously fed queue of 1 + n_rep * host_steps + 1 volumes, two in flight; a pass = host_steps consecutive results
+                # (time between the arrival of result p * host_steps and of result (p + 1) * host_steps): the rate of the queue
+                # itself -- filling it (the first volume's copy-in, ~5 ms) and draining it (the last copy-back) happen once per
+                # stream of volumes, not once per volume, and lie outside the passes
+                total = n_rep * args.host_steps + 1
+                stamps, pend = [], []
+                t_sub = time.perf_counter()
+                for i in range(total + 1):
+                    if i < total:
                         pend.append(inf.apply_async(vol))
-                        if len(pend) > 1:
+                    if len(pend) > 2 or i == total:
+                        while pend and (len(pend) > 2 or i == total):
                             box[0] = pend.pop(0).result()
-                    while pend:
-                        box[0] = pend.pop(0).result()
-
-                ms = []
-                for _ in range(n_rep):
-                    t0h = time.perf_counter()
-                    pipelined()
-                    ms.append((time.perf_counter() - t0h) / args.host_steps * 1e3)
+                            stamps.append(time.perf_counter())
+                ms = [(stamps[(p + 1) * args.host_steps] - stamps[p * args.host_steps]) / args.host_steps * 1e3 for p in range(n_rep)]
                 lmi["async_pipelined"] = leg(ms)
                 lmi["async_pipelined"]["identical_labels"] = bool(np.array_equal(box[0], ref_labels))
+                lmi["async_pipelined"]["first_result_after_ms"] = round((stamps[0] - t_sub) * 1e3, 3)
             box[0] = None
         # the reference's cost model for comparison: a brand-new pageable numpy array per call (page faults + unmapping), results kept alive
         keep = []
@@ -646,7 +649,9 @@ def main():
                             "lungmask_amd.LMInferer.apply(ndarray int16 [300,512,512]) -> ndarray uint8, the drop-in call itself (mask.py:212-232): "
                             "fresh_output_per_call = the reference's semantics, a result array of the caller's own per call -- a root array over a "
                             "page-locked block of the inferer's pool, given back by a finalizer when the result and all its views are gone (the loop "
-                            "drops each result, so two blocks alternate); reuse_output = LMInferer(reuse_output=True), one pageable array for every "
+                            "drops each result, so two blocks alternate); async_pipelined = LMInferer.apply_async, a continuously fed queue of volumes "
+                            "(lm_pipe_*: copy-in of volume i + 1 and copy-back of volume i beside the hot path of volume i; two in flight; the rate between "
+                            "consecutive results, queue fill / drain outside the passes); reuse_output = LMInferer(reuse_output=True), one pageable array for every "
                             "call; new_pageable_array_per_call = np.empty per call with the results kept alive (what a fresh allocation costs)"})
 
     if rank == 0:

@@ -111,8 +111,8 @@ int lm_set_precision(lm_engine* e, int mode);
  * such range limit).  lm_forward_dev / lm_forward_batches_dev / lm_apply_* therefore return only after the forward has
  * finished. */
 int lm_model_precision(lm_engine* e, int slot);
-/* Accuracy guard.  lm_model_load on a split-f16 engine (and lm_set_precision(e, 1) for models loaded before it) runs ONE deterministic
- * probe slice (256 x 256, phantom-like, in the network's [0, 1] input range) through the split-f16 and the exact-fp32 kernels of the
+/* Accuracy guard.  lm_model_load on a split-f16 engine (and lm_set_precision(e, 1) for models loaded before it) runs TWO deterministic
+ * probe slices (256 x 256: a phantom-like image and uniform noise, both in the network's [0, 1] input range) through the split-f16 and the exact-fp32 kernels of the
  * model and pins it to the exact-fp32 kernels -- with a notice on stderr -- when max |delta log-prob| exceeds the limit (environment
  * LM_ACC_GUARD, default 5e-4: half of the 1e-3 of the reference's fp32 result the engine is held to; "0" disables the probe).  A
  * checkpoint with a logit range or weight tails beyond what the split arithmetic resolves therefore cannot silently sit outside the
@@ -173,7 +173,7 @@ int lm_keep_largest_dev(lm_engine* e, uint8_t* mask_dev, int n, int h, int w, in
  * host, [2]=regions processed by the merge loop, [3]=regions merged, [4]=host replay in us. */
 /* ---- the same post-processing with the volume's slices spread over `world` ranks (multi-GPU pipeline) ----
  * Every rank holds a contiguous slab lab_slab_dev u8 [n][h][w] = slices [z0, z0+n) of a volume of n_total slices and
- * runs the voxel passes on its slab only; the slabs are tied together by six small exchanges the CALLER performs
+ * runs the voxel passes on its slab only; the slabs are tied together by four small exchanges (six with LM_SLAB_GRAPH=0, the voxel form of the second labelling) the CALLER performs
  * (torch.distributed all_gather over RCCL; csrc/slab_engine.hip describes each).  Protocol, identical on every rank:
  *     lm_slab_begin(...);
  *     do { len = lm_slab_pending(e);                       // int32 words this rank contributes
@@ -220,6 +220,25 @@ int lm_apply_host(lm_engine* e, int slot, int fill_slot, const void* vol_host, i
 #define LM_APPLY_OUT_SCRATCH 1u
 int lm_apply_host_ex(lm_engine* e, int slot, int fill_slot, const void* vol_host, int dtype, int n, int h, int w,
                      int batch_size, int volume_postprocessing, uint8_t* out_host, unsigned flags);
+
+/* ---- volumes QUEUED through one engine ("multi-volume queueing"; the reference's apply is one blocking call
+ *      per volume, mask.py:212-232) -------------------------------------------------------------------------------------------
+ * lm_apply_host crosses the host boundary inside the call: copy-in before the first kernel, copy-back behind the last.  With a
+ * stream of volumes both can run BESIDE the hot path of the neighbouring volumes.  The engine holds two resident input buffers and
+ * two result buffers (k = 0, 1); volume i uses k = i % 2:
+ *     lm_pipe_upload(e, k, vol_host, bytes)      copy-in on a stream of its own (returns when a pageable source has been staged:
+ *                                                call it from a thread of its own, ahead of the volume's turn);
+ *     lm_pipe_apply(e, k, slot, ...)             == lm_apply_dev on buffer k: waits ON THE DEVICE for the copy-in of k and for the
+ *                                                copy-back of the volume that used result buffer k before (two volumes earlier);
+ *     lm_pipe_download(e, k, out_host, bytes)    enqueues the copy-back on a third stream behind the hot path, returns at once;
+ *     lm_pipe_wait(e, k)                         blocks until that copy-back has arrived.
+ * The caller's part of the protocol: lm_pipe_upload(k) of volume i + 2 only after lm_pipe_apply(k) of volume i has returned, and
+ * out_host stays alive until lm_pipe_wait.  lm_pipe_upload may run on another thread than the other three (it touches nothing of
+ * theirs); lungmask_amd.LMInferer.apply_async is the binding.  Labels == lm_apply_host. */
+int lm_pipe_upload(lm_engine* e, int k, const void* vol_host, size_t bytes);
+int lm_pipe_apply(lm_engine* e, int k, int slot, int fill_slot, int dtype, int n, int h, int w, int batch_size, int volume_postprocessing);
+int lm_pipe_download(lm_engine* e, int k, uint8_t* out_host, size_t bytes);
+int lm_pipe_wait(lm_engine* e, int k);
 
 /* The batch loop of mask.py:173-187 in one call: n slices in batches of batch_size.  With two forward
  * lanes (default; lm_set_streams(e, 1) disables) consecutive batches alternate between two HIP streams and

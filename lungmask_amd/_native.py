@@ -109,6 +109,11 @@ class Library:
         L.lm_apply_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
         if hasattr(L, "lm_apply_host_ex"):  # (absent from older builds that tools/ab_forward.py may load for comparison)
             L.lm_apply_host_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_uint]
+        if hasattr(L, "lm_pipe_upload"):
+            L.lm_pipe_upload.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+            L.lm_pipe_apply.argtypes = [C.c_void_p] + [C.c_int] * 9
+            L.lm_pipe_download.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+            L.lm_pipe_wait.argtypes = [C.c_void_p, C.c_int]
         L.lm_profile_enable.argtypes = [C.c_void_p, C.c_int]
         L.lm_profile_reset.argtypes = [C.c_void_p]
         L.lm_profile_read.argtypes = [C.c_void_p, C.POINTER(KernelStat), C.c_int]
@@ -451,6 +456,24 @@ class Engine:
             self.L.lib.lm_apply_dev(self.h, slot, fill_slot, vol.ptr, LM_DTYPES[vol.dtype], n, h, w, int(batch_size), int(bool(volume_postprocessing)), out.ptr),
             "lm_apply_dev",
         )
+
+    # -- volumes queued through the engine (lm_pipe_*; LMInferer.apply_async drives them from two threads)
+    def pipe_upload(self, k: int, vol: Optional[np.ndarray]):
+        if vol is None:
+            self.L.check(self.L.lib.lm_pipe_upload(self.h, k, None, 0), "lm_pipe_upload")
+        else:
+            self.L.check(self.L.lib.lm_pipe_upload(self.h, k, vol.ctypes.data, vol.nbytes), "lm_pipe_upload")
+
+    def pipe_apply(self, k: int, slot: int, shape, dtype, fill_slot: int = -1, batch_size: int = 20, volume_postprocessing: bool = True):
+        n, h, w = (int(v) for v in shape)
+        self.L.check(self.L.lib.lm_pipe_apply(self.h, k, slot, fill_slot, LM_DTYPES[np.dtype(dtype)], n, h, w, int(batch_size), int(bool(volume_postprocessing))),
+                     "lm_pipe_apply")
+
+    def pipe_download(self, k: int, out: np.ndarray):
+        self.L.check(self.L.lib.lm_pipe_download(self.h, k, out.ctypes.data, out.nbytes), "lm_pipe_download")
+
+    def pipe_wait(self, k: int):
+        self.L.check(self.L.lib.lm_pipe_wait(self.h, k), "lm_pipe_wait")
 
     def apply(self, slot: int, vol: np.ndarray, fill_slot: int = -1, batch_size: int = 20, volume_postprocessing: bool = True,
               out: Optional[np.ndarray] = None, out_scratch: bool = False) -> np.ndarray:

@@ -80,6 +80,7 @@ void lm_engine_destroy(lm_engine* e) {
     e->post.release();
     e->slab.release();
     e->app.release();
+    e->pipe.release();
     (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -557,6 +558,103 @@ int lm_apply_host_ex(lm_engine* e, int slot, int fill_slot, const void* vol_host
         fprintf(stderr, "lm_apply_host: head H2D returned %.2f ms | helper: tail enqueued %.2f, pages %s %.2f | hot path returned %.2f | joined %.2f | extent known %.2f "
                 "(slices %d..%d rows %d..%d) | D2H done %.2f ms\n", t_head, t_tail, scratch ? "zeroed" : "touched", t_touch, t_apply, t_join, t_ext, ext[0], ext[1], ext[2], ext[3],
                 ms_since(t_start));
+    return LM_OK;
+}
+
+// ---- volumes queued through one engine (include/lungmask_hip.h: lm_pipe_*) ---------------------------------------------------
+static int pipe_init(lm_engine* e) {
+    lm_engine::Pipe& q = e->pipe;
+    if (q.up_stream) return LM_OK;
+    // The two copy streams get the HIGHEST priority class: same-priority streams share a small pool of hardware queues (see
+    // lm_engine_create), and a copy that lands on the queue of a forward lane holds that lane's kernels behind its barrier packet
+    // for the length of the copy -- measured: +2.9 ms per volume with ordinary streams (profiles/r06e_async_probe.log).  The streams
+    // carry nothing but copies, so the priority preempts nobody.
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (hipStreamCreateWithPriority(&q.up_stream, hipStreamNonBlocking, greatest) != hipSuccess ||
+        hipStreamCreateWithPriority(&q.out_stream, hipStreamNonBlocking, greatest) != hipSuccess) {
+        set_error("lm_pipe: creating the copy streams failed");
+        return LM_ERR_DEVICE;
+    }
+    for (int k = 0; k < 2; ++k)
+        if (hipEventCreateWithFlags(&q.uploaded[k], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&q.done[k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&q.copied[k], hipEventDisableTiming) != hipSuccess) {
+            set_error("lm_pipe: creating the events failed");
+            return LM_ERR_DEVICE;
+        }
+    return LM_OK;
+}
+
+int lm_pipe_upload(lm_engine* e, int k, const void* vol_host, size_t bytes) {
+    if (!e || (k != 0 && k != 1) || (!vol_host && bytes)) {
+        set_error("lm_pipe_upload: bad arguments");
+        return LM_ERR_INVALID;
+    }
+    LM_DEVICE(e);
+    LM_TRY(pipe_init(e));
+    lm_engine::Pipe& q = e->pipe;
+    LM_TRY(q.vol[k].reserve(bytes ? bytes : 16));
+    // A pageable source goes through a page-locked staging block of this buffer FIRST (a plain memcpy on this thread, which is why
+    // the call has a host thread of its own), then ONE truly asynchronous copy: handing the runtime a pageable pointer makes it stage
+    // the data itself, piece by piece, inside calls that the hot path's kernel launches on the other thread then queue behind.
+    const void* src = vol_host;
+    if (bytes && !host_range_is_pinned(vol_host, bytes)) {
+        if (q.staged[k]) LM_HIP(hipEventSynchronize(q.uploaded[k]));  // the previous copy out of this staging block
+        if (q.stage[k].reserve(bytes) == LM_OK) {
+            memcpy(q.stage[k].p, vol_host, bytes);
+            src = q.stage[k].p;
+            q.staged[k] = true;
+        }  // (no page-locked memory left: the runtime stages it)
+    }
+    if (bytes) LM_HIP(hipMemcpyAsync(q.vol[k].p, src, bytes, hipMemcpyHostToDevice, q.up_stream));
+    LM_HIP(hipEventRecord(q.uploaded[k], q.up_stream));
+    return LM_OK;
+}
+
+int lm_pipe_apply(lm_engine* e, int k, int slot, int fill_slot, int dtype, int n, int h, int w, int batch_size, int volume_postprocessing) {
+    if (!e || (k != 0 && k != 1) || n < 0 || h <= 0 || w <= 0) {
+        set_error("lm_pipe_apply: bad arguments");
+        return LM_ERR_INVALID;
+    }
+    LM_DEVICE(e);
+    LM_TRY(pipe_init(e));
+    lm_engine::Pipe& q = e->pipe;
+    const int esz = dtype == LM_I16 ? 2 : ((dtype == LM_I32 || dtype == LM_F32) ? 4 : ((dtype == LM_I64 || dtype == LM_F64) ? 8 : 0));
+    const size_t nvox = (size_t)n * h * w;
+    if (!esz || q.vol[k].cap < nvox * esz) {
+        set_error("lm_pipe_apply: buffer %d does not hold a volume of this size and dtype (lm_pipe_upload first)", k);
+        return LM_ERR_INVALID;
+    }
+    LM_TRY(q.out[k].reserve(nvox ? nvox : 16));
+    // the hot path reads vol[k] behind its copy-in and overwrites out[k] behind the copy-back of the volume that used it last
+    LM_HIP(hipStreamWaitEvent(e->stream, q.uploaded[k], 0));
+    if (q.copied_valid[k]) LM_HIP(hipStreamWaitEvent(e->stream, q.copied[k], 0));
+    LM_TRY(apply_volume(e, slot, fill_slot, q.vol[k].p, dtype, n, h, w, batch_size, volume_postprocessing, q.out[k].as<uint8_t>()));
+    LM_HIP(hipEventRecord(q.done[k], e->stream));
+    return LM_OK;
+}
+
+int lm_pipe_download(lm_engine* e, int k, uint8_t* out_host, size_t bytes) {
+    if (!e || (k != 0 && k != 1) || (!out_host && bytes) || !e->pipe.out_stream || e->pipe.out[k].cap < bytes) {
+        set_error("lm_pipe_download: bad arguments (lm_pipe_apply first)");
+        return LM_ERR_INVALID;
+    }
+    LM_DEVICE(e);
+    lm_engine::Pipe& q = e->pipe;
+    LM_HIP(hipStreamWaitEvent(q.out_stream, q.done[k], 0));
+    if (bytes) LM_HIP(hipMemcpyAsync(out_host, q.out[k].p, bytes, hipMemcpyDeviceToHost, q.out_stream));
+    LM_HIP(hipEventRecord(q.copied[k], q.out_stream));
+    q.copied_valid[k] = true;
+    return LM_OK;
+}
+
+int lm_pipe_wait(lm_engine* e, int k) {
+    if (!e || (k != 0 && k != 1) || !e->pipe.out_stream) {
+        set_error("lm_pipe_wait: bad arguments");
+        return LM_ERR_INVALID;
+    }
+    LM_DEVICE(e);
+    if (e->pipe.copied_valid[k]) LM_HIP(hipEventSynchronize(e->pipe.copied[k]));
     return LM_OK;
 }
 

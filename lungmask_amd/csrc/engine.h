@@ -164,6 +164,10 @@ struct SlabState {
     int phase = -1;          // next lm_slab_step to run (0..5); -1 = idle
     uint8_t* lab = nullptr;  // the caller's slab (device); receives the result
     int n1 = 0, n2 = 0;
+    // region-graph form (slab_engine.hip): the second labelling runs on the atom graph inside the first table merge -- four exchanges
+    // instead of six; keep_ids = the dense atom ids keeplut is indexed by (first labelling in the graph form, second one otherwise)
+    bool graph = false;
+    const int* keep_ids = nullptr;
     std::vector<int> labels, n3;  // label values with a kept component; atoms of each label's background labelling
     DevBuf ids2, ids3, first, flags, edges, pack, keeplut, holelut;
     long long pending = 0;  // ints of `pack` this rank contributes to the next exchange
@@ -280,6 +284,32 @@ struct lm_engine {
     lm::HostHelper helper;
     unsigned* range_flag = nullptr;       // device word of the f16 range guard (ConvParamsH3::range_flag)
     unsigned* range_flag_host = nullptr;  // pinned copy
+    // lm_pipe_* (capi.hip): volumes queued through one engine -- two resident input / result buffers, the copy-in of volume i + 1 and
+    // the copy-back of volume i on streams of their own beside the hot path of their neighbours
+    struct Pipe {
+        lm::DevBuf vol[2], out[2];
+        lm::HostBuf stage[2];  // page-locked staging of a pageable input volume
+        bool staged[2] = {false, false};
+        hipStream_t up_stream = nullptr, out_stream = nullptr;
+        hipEvent_t uploaded[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr}, copied[2] = {nullptr, nullptr};
+        bool copied_valid[2] = {false, false};
+        void release() {
+            for (int k = 0; k < 2; ++k) {
+                vol[k].release();
+                out[k].release();
+                stage[k].release();
+                staged[k] = false;
+                if (uploaded[k]) (void)hipEventDestroy(uploaded[k]);
+                if (done[k]) (void)hipEventDestroy(done[k]);
+                if (copied[k]) (void)hipEventDestroy(copied[k]);
+                uploaded[k] = done[k] = copied[k] = nullptr;
+                copied_valid[k] = false;
+            }
+            if (up_stream) (void)hipStreamDestroy(up_stream);
+            if (out_stream) (void)hipStreamDestroy(out_stream);
+            up_stream = out_stream = nullptr;
+        }
+    } pipe;
     // lm_dist_* (dist_rccl.hip): RCCL communicator of this engine's rank; world 0 = none, world 1 = no library involved
     void* dist_comm = nullptr;
     int dist_rank = 0, dist_world = 0;

@@ -15,6 +15,15 @@
 //   step 5: [host] union -> holes = background components without a flagged atom (fill_voids.fill, utils.py:352);
 //           write kept component + holes per label in ascending label order (utils.py:353-354).
 //
+// Region-graph form (round 6, the default; LM_SLAB_GRAPH=0 is the six-exchange voxel form above, kept as the A/B and test arm): the
+// second labelling -- the components of the MAPPED volume -- needs no voxel pass at all, as in the single-GPU path (post_engine.hip:
+// RegionGraph).  A component of the mapped volume is a union of atoms of the FIRST labelling that are 26-adjacent and carry the same
+// mapped label: the 6-adjacency is in the boundary records (halo neighbours included), the diagonal rest inside a slab comes from
+// diag_pairs, and across a slab face from the 26-adjacency of ALL atom pairs of the two face planes (the planes are exchanged
+// anyway; the same-label subset of those pairs is what ties atoms into regions).  Table 1 carries these pairs, the host finds every
+// label's kept component right behind the merge replay, and steps 1 (second half), 2 and 3 (first half) -- map, second labelling,
+// faces 2, table 2 -- do not run: four exchanges, two voxel labellings less.
+//
 // Exactness: regions/components are unions of atoms (two voxels adjacent across a slab face with equal labels
 // are in the same region whatever the slab cut), numbering needs only each region's first voxel, areas add,
 // boundary records are per voxel and are de-duplicated after the atom -> region mapping, and the merge replay is
@@ -151,10 +160,12 @@ int fetch_tables(lm_engine* e, const int32_t* gathered, long long stride, const 
     return LM_OK;
 }
 
-// ---- table 1 / 2: [n, nrec, nedge, 0 | area[n] | label[n] | first[n] | recs[nrec][8] | edges[nedge][2]]
+// ---- table 1 / 2: [n, nrec, nedge, ndiag | area[n] | label[n] | first[n] | recs[nrec][8] | edges[nedge][2] | diag[ndiag][2]]
+// (graph form: `edges` = ALL 26-adjacent atom pairs across the face to the next rank, whatever their labels; `diag` = pairs of this
+// slab's atoms that only touch diagonally)
 struct AtomTable {
-    int n = 0, nrec = 0, nedge = 0;
-    const int *area = nullptr, *lv = nullptr, *first = nullptr, *recs = nullptr, *edges = nullptr;
+    int n = 0, nrec = 0, nedge = 0, ndiag = 0;
+    const int *area = nullptr, *lv = nullptr, *first = nullptr, *recs = nullptr, *edges = nullptr, *diag = nullptr;
 };
 
 int parse_atom_tables(const SlabState& st, std::vector<AtomTable>& t, std::vector<int>& base) {
@@ -170,7 +181,9 @@ int parse_atom_tables(const SlabState& st, std::vector<AtomTable>& t, std::vecto
         a.n = v[0];
         a.nrec = v[1];
         a.nedge = v[2];
-        if (a.n < 0 || a.nrec < 0 || a.nedge < 0 || (size_t)4 + 3 * (size_t)a.n + 8 * (size_t)a.nrec + 2 * (size_t)a.nedge != v.size()) {
+        a.ndiag = v[3];
+        if (a.n < 0 || a.nrec < 0 || a.nedge < 0 || a.ndiag < 0 ||
+            (size_t)4 + 3 * (size_t)a.n + 8 * (size_t)a.nrec + 2 * (size_t)a.nedge + 2 * (size_t)a.ndiag != v.size()) {
             set_error("slab: malformed table of rank %d", r);
             return LM_ERR_INVALID;
         }
@@ -179,6 +192,7 @@ int parse_atom_tables(const SlabState& st, std::vector<AtomTable>& t, std::vecto
         a.first = a.lv + a.n;
         a.recs = a.first + a.n;
         a.edges = a.recs + 8 * (size_t)a.nrec;
+        a.diag = a.edges + 2 * (size_t)a.nedge;
         base[r + 1] = base[r] + a.n;
     }
     return LM_OK;
@@ -193,13 +207,16 @@ int unite_atoms(const SlabState& st, const std::vector<AtomTable>& t, const std:
                 set_error("slab: edge (%d,%d) of rank %d out of range", a, b, r);
                 return LM_ERR_INVALID;
             }
+            if (st.graph && t[r].lv == t[r].area + t[r].n && t[r].lv[a - 1] != t[r + 1].lv[b - 1]) continue;  // (all-pairs edges: regions join equal labels only)
             uf.unite(base[r] + a - 1, base[r + 1] + b - 1);
         }
     return LM_OK;
 }
 
-// step 1 host part: LUT (final label value) of this rank's atoms
-int merge_regions(lm_engine* e, std::vector<uint8_t>& my_lut) {
+// step 1 host part: LUT (final label value) of this rank's atoms.  Graph form (keeplut != nullptr): also, on the atom graph, every
+// label's kept component (utils.py:355-356 / :390-404) -- keeplut[atom] = its mapped label when the atom belongs to it -- and the
+// labels that have one.
+int merge_regions(lm_engine* e, std::vector<uint8_t>& my_lut, std::vector<uint8_t>* keeplut = nullptr, std::vector<int>* labels = nullptr) {
     SlabState& st = e->slab;
     std::vector<AtomTable> t;
     std::vector<int> base;
@@ -272,6 +289,71 @@ int merge_regions(lm_engine* e, std::vector<uint8_t>& my_lut) {
     replay_merge(R, area.data(), lv.data(), recs.data(), recs.size(), st.spare, st.skip_below, lut, info);
     my_lut.assign((size_t)t[st.rank].n + 1, 0);
     for (int a = 0; a < t[st.rank].n; ++a) my_lut[a + 1] = lut[region[base[st.rank] + a]];
+    if (keeplut == nullptr) return LM_OK;
+    // ---- the second labelling on the atom graph: atoms with the same mapped label that are 26-adjacent
+    std::vector<uint8_t> mlab(G);
+    for (int g = 0; g < G; ++g) mlab[g] = lut[region[g]];
+    UnionFind uf2(G);
+    auto join = [&](int ga, int gb) {
+        if (mlab[ga] && mlab[ga] == mlab[gb]) uf2.unite(ga, gb);
+    };
+    for (int r = 0; r < st.world; ++r) {
+        for (int j = 0; j < t[r].nrec; ++j) {  // 6-adjacency (ranges were checked above)
+            const int* q = t[r].recs + 8 * (size_t)j;
+            const int ga = base[r] + q[0] - 1;
+            for (int i = 0; i < 6 && q[1 + i]; ++i) {
+                const int code = q[1 + i], id = code & ~HALO_MASK;
+                const int rr = (code & HALO_LO) ? r - 1 : ((code & HALO_HI) ? r + 1 : r);
+                join(ga, base[rr] + id - 1);
+            }
+        }
+        for (int j = 0; j < t[r].ndiag; ++j) {  // diagonal-only neighbours inside the slab
+            const int a = t[r].diag[2 * j], b = t[r].diag[2 * j + 1];
+            if (a < 1 || a > t[r].n || b < 1 || b > t[r].n) {
+                set_error("slab: diagonal pair (%d,%d) of rank %d out of range", a, b, r);
+                return LM_ERR_INVALID;
+            }
+            join(base[r] + a - 1, base[r] + b - 1);
+        }
+        for (int j = 0; j < t[r].nedge; ++j) join(base[r] + t[r].edges[2 * j] - 1, base[r + 1] + t[r].edges[2 * j + 1] - 1);  // across the face (checked by unite_atoms)
+    }
+    std::vector<int> cf2(G, 0x7fffffff);
+    std::vector<long long> ca2(G, 0);
+    long long nonzero = 0;
+    for (int r = 0; r < st.world; ++r)
+        for (int a = 0; a < t[r].n; ++a) {
+            const int g = base[r] + a;
+            if (!mlab[g]) continue;
+            const int c = uf2.find(g);
+            ca2[c] += t[r].area[a];
+            cf2[c] = std::min(cf2[c], t[r].first[a]);
+            nonzero += t[r].area[a];
+        }
+    // largest area; on ties the component with the LAST first voxel (merge_components' rule, the single-GPU path's key)
+    int best[256];
+    for (int i = 0; i < 256; ++i) best[i] = -1;
+    for (int g = 0; g < G; ++g) {
+        if (!mlab[g] || uf2.find(g) != g) continue;
+        const int L = mlab[g], b = best[L];
+        if (b < 0 || ca2[g] > ca2[b] || (ca2[g] == ca2[b] && cf2[g] > cf2[b])) best[L] = g;
+    }
+    // utils.py:355 `np.unique(outmask_mapped)[1:]`: without a background voxel in the mapped volume the smallest LABEL is dropped
+    bool drop_smallest = G > 0 && nonzero == (long long)st.n_total * st.H * st.W;
+    labels->clear();
+    for (int L = 1; L < 256; ++L)
+        if (best[L] >= 0) {
+            if (drop_smallest) {
+                drop_smallest = false;
+                best[L] = -1;
+                continue;
+            }
+            labels->push_back(L);
+        }
+    keeplut->assign((size_t)t[st.rank].n + 1, 0);
+    for (int a = 0; a < t[st.rank].n; ++a) {
+        const int g = base[st.rank] + a, L = mlab[g];
+        if (L && best[L] == uf2.find(g)) (*keeplut)[a + 1] = (uint8_t)L;
+    }
     return LM_OK;
 }
 
@@ -385,13 +467,15 @@ int write_header(lm_engine* e, int* dst, int a, int b, int c, int d) {
 }
 
 // table 1 / 2 from ws.area / ws.labval / st.first (+ records, + edges)
-int pack_atom_table(lm_engine* e, int n, unsigned nrec, unsigned nedge) {
+int pack_atom_table(lm_engine* e, int n, unsigned nrec, unsigned nedge, unsigned ndiag = 0) {
     SlabState& st = e->slab;
     PostWorkspace& ws = e->post;
-    const size_t len = 4 + 3 * (size_t)n + 8 * (size_t)nrec + 2 * (size_t)nedge;
+    const size_t len = 4 + 3 * (size_t)n + 8 * (size_t)nrec + 2 * (size_t)nedge + 2 * (size_t)ndiag;
     LM_TRY(st.pack.reserve(len * 4));
     int* pk = st.pack.as<int>();
-    LM_TRY(write_header(e, pk, n, (int)nrec, (int)nedge, 0));
+    LM_TRY(write_header(e, pk, n, (int)nrec, (int)nedge, (int)ndiag));
+    // (diag_pairs writes (smaller id << 32 | larger id) as one 64-bit word: two ints per pair, the order inside a pair is immaterial)
+    if (ndiag) LM_HIP(hipMemcpyAsync(pk + 4 + 3 * (size_t)n + 8 * (size_t)nrec + 2 * (size_t)nedge, ws.pairs.p, (size_t)ndiag * 8, hipMemcpyDeviceToDevice, e->stream));
     if (n) {
         LM_HIP(hipMemcpyAsync(pk + 4, ws.area.as<int>() + 1, (size_t)n * 4, hipMemcpyDeviceToDevice, e->stream));
         LM_K(widen_u8(ws.labval.as<uint8_t>() + 1, pk + 4 + n, (size_t)n, e->stream));
@@ -401,6 +485,40 @@ int pack_atom_table(lm_engine* e, int n, unsigned nrec, unsigned nedge) {
     if (nedge) LM_HIP(hipMemcpyAsync(pk + 4 + 3 * (size_t)n + 8 * (size_t)nrec, st.edges.p, (size_t)nedge * 8, hipMemcpyDeviceToDevice, e->stream));
     st.pending = (long long)len;
     st.pending_uniform = false;
+    return LM_OK;
+}
+
+// per kept label (st.labels; membership: keeplut[keep_ids[v]] == label): the 6-connected labelling of the component's complement
+// inside the slab, atoms flagged when they touch a face of the WHOLE volume, and the first / last plane of every labelling -> faces 3
+int background_faces(lm_engine* e) {
+    SlabState& st = e->slab;
+    PostWorkspace& ws = e->post;
+    hipStream_t s = e->stream;
+    const Dims d{st.n, st.H, st.W};
+    const size_t nvox = d.nvox(), HW = (size_t)st.H * st.W, last = (size_t)(st.n - 1) * HW;
+    const int K = (int)st.labels.size();
+    st.n3.assign(K, 0);
+    LM_TRY(st.ids3.reserve(std::max<size_t>((size_t)K, 1) * nvox * 4));
+    for (int k = 0; k < K; ++k) {
+        LM_K(lut_complement(st.keep_ids, st.keeplut.as<uint8_t>(), (uint8_t)st.labels[k], ws.bg.as<uint8_t>(), nvox, s));
+        LM_TRY(label_slab(e, ws.bg.as<uint8_t>(), ws.bgparent.as<int>(), st.ids3.as<int>() + (size_t)k * nvox, d, false, &st.n3[k], "post_ccl6_background"));
+    }
+    size_t nflags = 0;
+    for (int k = 0; k < K; ++k) nflags += (size_t)st.n3[k] + 1;
+    LM_TRY(st.flags.reserve(std::max<size_t>(nflags, 1) * 4));
+    LM_HIP(hipMemsetAsync(st.flags.p, 0, std::max<size_t>(nflags, 1) * 4, s));
+    LM_TRY(st.pack.reserve(std::max<size_t>((size_t)K, 1) * 2 * HW * 4));
+    size_t foff = 0;
+    for (int k = 0; k < K; ++k) {
+        const int* ids3 = st.ids3.as<int>() + (size_t)k * nvox;
+        // faces of the WHOLE volume: lateral faces, the first slice of rank 0, the last slice of the last rank
+        LM_K(atom_face_flags(ids3, d, st.z0 == 0, st.z0 + st.n == st.n_total, st.flags.as<int>() + foff, s));
+        foff += (size_t)st.n3[k] + 1;
+        LM_HIP(hipMemcpyAsync(st.pack.as<int>() + (size_t)(2 * k) * HW, ids3, HW * 4, hipMemcpyDeviceToDevice, s));
+        LM_HIP(hipMemcpyAsync(st.pack.as<int>() + (size_t)(2 * k + 1) * HW, ids3 + last, HW * 4, hipMemcpyDeviceToDevice, s));
+    }
+    st.pending = (long long)((size_t)K * 2 * HW);
+    st.pending_uniform = true;  // K is derived from the gathered tables: the same on every rank
     return LM_OK;
 }
 
@@ -424,6 +542,9 @@ int slab_begin(lm_engine* e, uint8_t* lab, int n, int h, int w, int rank, int wo
     st.rank = rank; st.world = world; st.n = n; st.H = h; st.W = w; st.z0 = z0; st.n_total = n_total; st.skip_below = skip_below;
     st.spare.assign(spare, spare + (spare ? n_spare : 0));
     st.lab = lab;
+    static const bool graph_ok = [] { const char* v = getenv("LM_SLAB_GRAPH"); return !(v && v[0] == '0'); }();
+    st.graph = graph_ok;
+    st.keep_ids = nullptr;
     const Dims d{n, h, w};
     const size_t nvox = d.nvox();
     PostWorkspace& ws = e->post;
@@ -494,16 +615,50 @@ int slab_step(lm_engine* e, const int32_t* gathered, long long stride, const lon
                 if (nrec <= cap) break;
                 cap = nrec;
             }
-            unsigned nedge = 0;
+            unsigned nedge = 0, ndiag = 0;
             if (has_next) {
                 const int* mine = gathered + (size_t)st.rank * stride;
                 const int* next = gathered + (size_t)(st.rank + 1) * stride;
-                LM_TRY(cross_edges(e, mine + 3 * HW, mine + 2 * HW, next + HW, next, d, true, 0, &nedge));
+                // graph form: ALL 26-adjacent atom pairs across the face (labels ignored); the host picks the equal-label ones for the regions
+                if (st.graph) LM_TRY(cross_edges(e, mine + 3 * HW, nullptr, next + HW, nullptr, d, true, 0, &nedge));
+                else LM_TRY(cross_edges(e, mine + 3 * HW, mine + 2 * HW, next + HW, next, d, true, 0, &nedge));
             }
-            LM_TRY(pack_atom_table(e, st.n1, nrec, nedge));
+            if (st.graph) {  // pairs of this slab's atoms that only touch diagonally
+                unsigned* pcount_dev = ws.scalars.as<unsigned>() + 3;
+                unsigned pcap = (unsigned)std::max<size_t>(ws.pairs.cap / 8, 1u << 16);
+                for (;;) {
+                    LM_TRY(ws.pairs.reserve((size_t)pcap * 8));
+                    LM_HIP(hipMemsetAsync(pcount_dev, 0, sizeof(unsigned), s));
+                    {
+                        ProfScope ps(e, "post_diag_pairs", (double)nvox * 2);
+                        LM_K(diag_pairs(st.lab, ws.ids.as<int>(), d, ws.pairs.as<unsigned long long>(), pcount_dev, pcap, s));
+                    }
+                    LM_HIP(hipMemcpyAsync(&ndiag, pcount_dev, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+                    LM_HIP(hipStreamSynchronize(s));
+                    if (ndiag <= pcap) break;
+                    pcap = ndiag;
+                }
+            }
+            LM_TRY(pack_atom_table(e, st.n1, nrec, nedge, ndiag));
             break;
         }
-        case 1: {  // table 1 -> LUT, mapped slab, its labelling -> faces 2
+        case 1: {  // table 1 -> LUT, mapped slab, its labelling -> faces 2   (graph form: -> kept components, background labelling -> faces 3)
+            if (st.graph) {
+                LM_TRY(fetch_tables(e, gathered, stride, lens));
+                std::vector<uint8_t> lut, keep;
+                LM_TRY(merge_regions(e, lut, &keep, &st.labels));
+                if ((int)keep.size() != st.n1 + 1) {
+                    set_error("lm_slab_step(1): table does not match this rank's atoms");
+                    return LM_ERR_INVALID;
+                }
+                LM_TRY(st.keeplut.reserve(keep.size()));
+                LM_HIP(hipMemcpyAsync(st.keeplut.p, keep.data(), keep.size(), hipMemcpyHostToDevice, s));
+                LM_HIP(hipStreamSynchronize(s));
+                st.keep_ids = ws.ids.as<int>();
+                LM_TRY(background_faces(e));
+                st.phase = 4;  // faces 3 -> table 3 comes next: steps 2 and 3 do not exist in this form
+                return LM_OK;
+            }
             LM_TRY(fetch_tables(e, gathered, stride, lens));
             std::vector<uint8_t> lut;
             LM_TRY(merge_regions(e, lut));
@@ -548,30 +703,8 @@ int slab_step(lm_engine* e, const int32_t* gathered, long long stride, const lon
             LM_TRY(st.keeplut.reserve(keep.size()));
             LM_HIP(hipMemcpyAsync(st.keeplut.p, keep.data(), keep.size(), hipMemcpyHostToDevice, s));
             LM_HIP(hipStreamSynchronize(s));
-            const int K = (int)st.labels.size();
-            st.n3.assign(K, 0);
-            LM_TRY(st.ids3.reserve(std::max<size_t>((size_t)K, 1) * nvox * 4));
-            for (int k = 0; k < K; ++k) {
-                LM_K(lut_complement(st.ids2.as<int>(), st.keeplut.as<uint8_t>(), (uint8_t)st.labels[k], ws.bg.as<uint8_t>(), nvox, s));
-                LM_TRY(label_slab(e, ws.bg.as<uint8_t>(), ws.bgparent.as<int>(), st.ids3.as<int>() + (size_t)k * nvox, d, false, &st.n3[k],
-                                  "post_ccl6_background"));
-            }
-            size_t nflags = 0;
-            for (int k = 0; k < K; ++k) nflags += (size_t)st.n3[k] + 1;
-            LM_TRY(st.flags.reserve(std::max<size_t>(nflags, 1) * 4));
-            LM_HIP(hipMemsetAsync(st.flags.p, 0, std::max<size_t>(nflags, 1) * 4, s));
-            LM_TRY(st.pack.reserve(std::max<size_t>((size_t)K, 1) * 2 * HW * 4));
-            size_t foff = 0;
-            for (int k = 0; k < K; ++k) {
-                const int* ids3 = st.ids3.as<int>() + (size_t)k * nvox;
-                // faces of the WHOLE volume: lateral faces, the first slice of rank 0, the last slice of the last rank
-                LM_K(atom_face_flags(ids3, d, st.z0 == 0, st.z0 + st.n == st.n_total, st.flags.as<int>() + foff, s));
-                foff += (size_t)st.n3[k] + 1;
-                LM_HIP(hipMemcpyAsync(st.pack.as<int>() + (size_t)(2 * k) * HW, ids3, HW * 4, hipMemcpyDeviceToDevice, s));
-                LM_HIP(hipMemcpyAsync(st.pack.as<int>() + (size_t)(2 * k + 1) * HW, ids3 + last, HW * 4, hipMemcpyDeviceToDevice, s));
-            }
-            st.pending = (long long)((size_t)K * 2 * HW);
-            st.pending_uniform = true;  // K is derived from the gathered tables: the same on every rank
+            st.keep_ids = st.ids2.as<int>();
+            LM_TRY(background_faces(e));
             break;
         }
         case 4: {  // faces 3 -> table 3
@@ -635,7 +768,7 @@ int slab_step(lm_engine* e, const int32_t* gathered, long long stride, const lon
             off = 0;
             for (int k = 0; k < K; ++k) {  // ascending label order: later labels overwrite (utils.py:353-354)
                 ProfScope ps(e, "post_fill_write", (double)nvox * 13);
-                LM_K(fill_write_lut(st.ids2.as<int>(), st.keeplut.as<uint8_t>(), st.ids3.as<int>() + (size_t)k * nvox, st.holelut.as<uint8_t>() + off,
+                LM_K(fill_write_lut(st.keep_ids, st.keeplut.as<uint8_t>(), st.ids3.as<int>() + (size_t)k * nvox, st.holelut.as<uint8_t>() + off,
                                     (uint8_t)st.labels[k], out, nvox, s));
                 off += hole[k].size();
             }

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import sys
 import threading
 import warnings
 import weakref
@@ -172,6 +173,146 @@ class _ShardedApply:
         self.pipes = []
 
 
+class AsyncResult:
+    """What `LMInferer.apply_async` returns: `result()` blocks until the volume's labels have arrived and returns the uint8 array
+    (or raises what the call raised); `done()` does not block."""
+
+    def __init__(self):
+        self._enqueued = threading.Event()  # the hot path has run and the copy-back is enqueued (or the call failed)
+        self._lock = threading.Lock()
+        self._res = None
+        self._exc = None
+        self._wait = None  # waits for the copy-back; None once it is known to have arrived
+
+    def _finish(self):
+        with self._lock:
+            w, self._wait = self._wait, None
+        if w is not None:
+            w()
+
+    def done(self) -> bool:
+        return self._enqueued.is_set() and self._wait is None
+
+    def result(self) -> np.ndarray:
+        self._enqueued.wait()
+        if self._exc is not None:
+            raise self._exc
+        self._finish()
+        return self._res
+
+
+class _AsyncPipe:
+    """Volumes queued through ONE engine (include/lungmask_hip.h: lm_pipe_*): an uploader thread copies volume i + 1 into the
+    engine's other input buffer while the runner thread has volume i on the hot path; the copy-back of volume i runs on a third
+    stream beside volume i + 1.  Two volumes in flight, results in submission order."""
+
+    def __init__(self, inferer):
+        import queue
+
+        self.inf = inferer
+        self.eng = inferer.engine
+        self.eng.pipe_upload(0, None)  # streams and events exist before the two threads touch them
+        self.jobs = {}
+        self.seq = 0
+        self.up_q, self.run_q = queue.Queue(), queue.Queue()
+        self.idle = threading.Condition()
+        self.pending = 0
+        self.timing = os.environ.get("LM_ASYNC_TIMING") == "1"  # per-volume breakdown of the two threads on stderr
+        self.threads = [threading.Thread(target=self._uploader, name="lungmask_amd-upload", daemon=True),
+                        threading.Thread(target=self._runner, name="lungmask_amd-run", daemon=True)]
+        for t in self.threads:
+            t.start()
+
+    def submit(self, vol: np.ndarray) -> AsyncResult:
+        h = AsyncResult()
+        job = dict(seq=self.seq, k=self.seq % 2, vol=vol, handle=h, uploaded=threading.Event(), computed=threading.Event(), error=None)
+        self.seq += 1
+        with self.idle:
+            self.pending += 1
+        self.jobs[job["seq"]] = job
+        self.up_q.put(job)
+        self.run_q.put(job)
+        return h
+
+    def _uploader(self):
+        import time
+
+        while True:
+            job = self.up_q.get()
+            if job is None:
+                return
+            try:
+                prev = self.jobs.get(job["seq"] - 2)
+                if prev is not None:
+                    prev["computed"].wait()  # the hot path of the volume that used this input buffer has returned
+                t0 = time.perf_counter()
+                self.eng.pipe_upload(job["k"], job["vol"])
+                if self.timing:
+                    sys.stderr.write("apply_async: volume %d copy-in call %.2f ms\n" % (job["seq"], (time.perf_counter() - t0) * 1e3))
+            except BaseException as exc:  # noqa: BLE001
+                job["error"] = exc
+            job["uploaded"].set()
+
+    def _runner(self):
+        import time
+
+        inf, eng = self.inf, self.eng
+        t_prev = time.perf_counter()
+        while True:
+            job = self.run_q.get()
+            if job is None:
+                return
+            h = job["handle"]
+            try:
+                t0 = time.perf_counter()
+                job["uploaded"].wait()
+                if job["error"] is not None:
+                    raise job["error"]
+                vol = job["vol"]
+                t1 = time.perf_counter()
+                res = inf._result_array(vol.shape)
+                t2 = time.perf_counter()
+                eng.pipe_apply(job["k"], 0, vol.shape, vol.dtype, fill_slot=inf.fill_slot, batch_size=inf.batch_size,
+                               volume_postprocessing=inf.volume_postprocessing)
+                t3 = time.perf_counter()
+                job["computed"].set()
+                prev = self.jobs.pop(job["seq"] - 2, None)
+                if prev is not None:
+                    prev["handle"]._finish()  # (its copy-back is long done: this volume's hot path waited for it on the device)
+                eng.pipe_download(job["k"], res)
+                if self.timing:
+                    sys.stderr.write("apply_async: volume %d waited for its copy-in %.2f ms, result array %.2f, hot path %.2f, hand-over %.2f (idle before: %.2f)\n" % (
+                        job["seq"], (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (time.perf_counter() - t3) * 1e3, (t0 - t_prev) * 1e3))
+                t_prev = time.perf_counter()
+                h._res = res
+                k = job["k"]
+                h._wait = lambda: eng.pipe_wait(k)
+            except BaseException as exc:  # noqa: BLE001
+                h._exc = exc
+                job["computed"].set()
+            job["vol"] = None
+            h._enqueued.set()
+            with self.idle:
+                self.pending -= 1
+                self.idle.notify_all()
+
+    def flush(self):
+        """Returns when every submitted volume has left the hot path and its copy-back has arrived."""
+        with self.idle:
+            self.idle.wait_for(lambda: self.pending == 0)
+        for job in list(self.jobs.values()):
+            if job["handle"]._exc is None:
+                job["handle"]._finish()
+
+    def close(self):
+        self.flush()
+        self.up_q.put(None)
+        self.run_q.put(None)
+        for t in self.threads:
+            t.join(timeout=10)
+        self.jobs.clear()
+
+
 class LMInferer:
     """mask.py:71-232."""
 
@@ -215,6 +356,7 @@ class LMInferer:
         # stays the default; a fresh 79 MB array per 300-slice volume costs ~3-4 ms of page faults and unmapping.
         self.reuse_output = reuse_output
         self._out = None
+        self._async = None  # apply_async's pipeline (two host threads), created on first use
         self._pool = None  # page-locked result blocks (see _result_array); created with the engine below
         if force_cpu:
             # mask.py:118-134 selects torch-CPU.  This engine has no CPU compute path by design, so by default the request is an
@@ -290,6 +432,9 @@ class LMInferer:
     def close(self):
         """Releases the idle result blocks and the engine(s) this object created.  Results already handed out stay valid (their
         blocks are freed when they are dropped)."""
+        if getattr(self, "_async", None) is not None:
+            self._async.close()
+            self._async = None
         if getattr(self, "_pool", None) is not None:
             self._pool.close()
         sh = getattr(self, "_shard", None)
@@ -311,6 +456,44 @@ class LMInferer:
         except Exception:
             pass
 
+    def apply_async(self, image) -> AsyncResult:
+        """`apply` for a STREAM of volumes (extension; SURVEY.md section 8f #4, "multi-volume queueing"): returns at once with a handle
+        whose `result()` is what `apply(image)` would have returned.  Volumes go through the engine in submission order, two in
+        flight: the copy-in of the next volume and the copy-back of the previous one run beside the hot path of the current one
+        (lm_pipe_*), so a caller that keeps the queue fed sees the device-resident rate.  `image` must stay unchanged until
+        `result()` returns.  Inputs that need more than the one call (a re-orientation to LPS, several GPUs, an empty volume) are
+        computed by `apply` itself, in order."""
+        done = AsyncResult()
+        eligible = isinstance(image, np.ndarray) and image.ndim == 3 and image.shape[0] > 0 and self._shard is None and hasattr(self.engine.L.lib, "lm_pipe_upload")
+        if eligible:
+            try:
+                vol = np.ascontiguousarray(self._engine_dtype(image))
+            except TypeError as exc:
+                done._exc = exc
+                done._enqueued.set()
+                return done
+            if self._async is None:
+                self._async = _AsyncPipe(self)
+            return self._async.submit(vol)
+        try:
+            done._res = self.apply(image)  # (waits for the queued volumes first)
+        except BaseException as exc:  # noqa: BLE001
+            done._exc = exc
+        done._enqueued.set()
+        return done
+
+    @staticmethod
+    def _engine_dtype(inimg_raw: np.ndarray) -> np.ndarray:
+        """The dtypes the engine pre-processes on the device; everything else value-preserving widened (numpy mode of mask.py:153-155)."""
+        if inimg_raw.dtype not in (np.int16, np.int32, np.int64, np.float32, np.float64):
+            if inimg_raw.dtype.kind in "ib" or inimg_raw.dtype.kind == "u" and inimg_raw.dtype.itemsize < 8:
+                # value preserving; np.clip(-1024, 600) then behaves as for a wider signed type
+                return inimg_raw.astype(np.int32 if inimg_raw.dtype.itemsize < 4 else np.int64)
+            if inimg_raw.dtype == np.float16:
+                return inimg_raw.astype(np.float32)  # value preserving
+            raise TypeError(f"lungmask_amd: unsupported volume dtype {inimg_raw.dtype}")
+        return inimg_raw
+
     def apply(self, image, out: Optional[np.ndarray] = None) -> np.ndarray:
         """mask.py:212-232 (+ _inference :141-210).  `image`: numpy volume [n,h,w], a `volume_io.Volume`, or a SimpleITK
         image.  Images with a direction matrix are brought to LPS and back (mask.py:156-164, 204-208) by an index
@@ -330,14 +513,9 @@ class LMInferer:
                 inimg_raw, direction = sitk.GetArrayFromImage(image), image.GetDirection()
             if volume_io.orientation_code(direction) != "LPS":
                 axes, flips = volume_io.lps_transform(direction)
-        if inimg_raw.dtype not in (np.int16, np.int32, np.int64, np.float32, np.float64):
-            if inimg_raw.dtype.kind in "ib" or inimg_raw.dtype.kind == "u" and inimg_raw.dtype.itemsize < 8:
-                # value preserving; np.clip(-1024, 600) then behaves as for a wider signed type
-                inimg_raw = inimg_raw.astype(np.int32 if inimg_raw.dtype.itemsize < 4 else np.int64)
-            elif inimg_raw.dtype == np.float16:
-                inimg_raw = inimg_raw.astype(np.float32)  # value preserving
-            else:
-                raise TypeError(f"lungmask_amd: unsupported volume dtype {inimg_raw.dtype}")
+        inimg_raw = self._engine_dtype(inimg_raw)
+        if self._async is not None:
+            self._async.flush()  # one engine, one hot path at a time: the queued volumes first
         if self.fillmodel is not None:
             logger.info(f"Apply: {self.modelname}")
             logger.info(f"Apply: {self.fillmodel}")

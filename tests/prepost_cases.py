@@ -292,6 +292,46 @@ def check_postprocess_diagonal_adversarial(eng, n_iter=60):
             assert np.array_equal(out, ref), (it, shape, kind, spare, skip, int((out != ref).sum()))
 
 
+def check_slab_postprocess_diagonal_adversarial(engines, n_iter=24):
+    """The slab protocol's region-graph form (csrc/slab_engine.hip: the second labelling on the ATOM graph -- 6-adjacency from the
+    boundary records incl. halo neighbours, diagonal pairs inside a slab, all 26-adjacent atom pairs across a slab face): the
+    volumes of check_postprocess_diagonal_adversarial (label noise, volumes without a background voxel, diagonal lattices) cut into
+    slabs at every position, with and without a spare label, against the oracle."""
+    import os
+
+    from lungmask_amd.pipeline import postprocess_slabs_in_process, shard_bounds
+    from oracle.make_golden import random_blobs
+
+    rng = np.random.default_rng(321)
+    shapes = [(5, 12, 12), (4, 10, 14), (6, 9, 11), (3, 16, 8), (2, 7, 9)]
+    for it in range(n_iter):
+        shape = shapes[it % 5]
+        kind = it % 4
+        if kind == 0:
+            lab = rng.integers(0, 4, shape).astype(np.uint8)
+        elif kind == 1:
+            lab = random_blobs(rng, shape, 3, 6, 0.4)
+            lab[rng.random(shape) < 0.15] = rng.integers(1, 4)
+        elif kind == 2:
+            lab = rng.integers(1, 4, shape).astype(np.uint8)
+        else:
+            lab = np.zeros(shape, np.uint8)
+            zz, yy, xx = np.indices(shape)
+            m = (zz + yy + xx) % 2 == 0
+            lab[m] = (1 + ((zz + 2 * yy + 3 * xx) % 3 == 0))[m]
+            lab[rng.random(shape) < 0.1] = 3
+        for spare, skip in (((), 3), ((3,), 3), ((), 1)):
+            ref = po.postprocessing(lab.copy(), spare=list(spare), skip_below=skip)
+            for world in range(2, min(len(engines), shape[0]) + 1):
+                cuts = [shard_bounds(shape[0], world)]
+                if world == 2:
+                    cuts += [[0, c, shape[0]] for c in range(1, shape[0]) if [0, c, shape[0]] != cuts[0]]
+                for b in cuts:
+                    out = postprocess_slabs_in_process(engines[:world], lab, b, spare, skip)
+                    assert np.array_equal(out, ref), (it, shape, kind, spare, skip, b, int((out != ref).sum()))
+                    assert postprocess_slabs_in_process.last_rounds == (6 if os.environ.get("LM_SLAB_GRAPH") == "0" else 4)
+
+
 def check_bbox_klc(eng):
     """utils.bbox_3D (utils.py:361-387) and utils.keep_largest_connected_component (utils.py:390-404) as calls of their own:
     every `klc*` golden (outputs of the reference's own functions, oracle/_ref_runner.py), the reference's test vector

@@ -598,3 +598,42 @@ def test_apply_host_scratch_output_copies_back_only_the_labelled_slab(gpu_engine
     del second
     third = inf.apply(vol)  # ... handed out again with the reversed volume's labels in it
     assert np.array_equal(first, expect) and np.array_equal(third, expect)
+
+
+def test_apply_async_equals_apply(gpu_engine):
+    """`LMInferer.apply_async` (lm_pipe_*): a stream of volumes -- different contents, sizes and dtypes, two in flight,
+    copy-in / copy-back beside the neighbours' hot path -- gives, volume for volume, the bytes `apply` gives; a blocking `apply`
+    in between waits for the queue; the fused mode goes the same way; results held across later volumes stay intact."""
+    from lungmask_amd.mask import LMInferer
+
+    sd3, sd6 = uo.synthetic_state_dict(3), uo.synthetic_state_dict(6)
+    base = po.phantom(44, 512, 512, seed=11)
+    vols = [base, base[::-1].copy(), base[4:29].astype(np.int32), base[:21, 40:420, 30:450].copy(), base.astype(np.float32) + 0.25, base[10:12].copy(), base]
+    inf = LMInferer(state_dict=sd3, engine=gpu_engine)
+    try:
+        expect = [inf.apply(v).copy() for v in vols]
+        pend, got = [], []
+        for v in vols:
+            pend.append(inf.apply_async(v))
+            if len(pend) > 2:
+                got.append(pend.pop(0).result())
+        mid = inf.apply(vols[1])  # (a blocking call with two volumes queued: waits for them, then runs)
+        while pend:
+            got.append(pend.pop(0).result())
+        assert np.array_equal(mid, expect[1])
+        for i, (g, e) in enumerate(zip(got, expect)):
+            assert g.dtype == np.uint8 and g.shape == e.shape and np.array_equal(g, e), i
+        assert got[0].any() and not np.shares_memory(got[0], got[6])
+        # many short volumes back to back (the ring of two buffers turns over quickly)
+        hs = [inf.apply_async(vols[5]) for _ in range(9)]
+        assert all(np.array_equal(h.result(), expect[5]) for h in hs)
+    finally:
+        inf.close()
+    fused = LMInferer(modelname="LTRCLobes", fillmodel="R231", state_dict=sd6, fill_state_dict=sd3, engine=gpu_engine)
+    try:
+        e0, e1 = fused.apply(vols[0]).copy(), fused.apply(vols[3]).copy()
+        h0, h1 = fused.apply_async(vols[0]), fused.apply_async(vols[3])
+        assert np.array_equal(h1.result(), e1) and np.array_equal(h0.result(), e0)
+    finally:
+        fused.close()
+        gpu_engine.load_state_dict(0, sd3)

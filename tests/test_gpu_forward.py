@@ -364,7 +364,7 @@ def test_batchnorm_scales_of_any_sign_and_magnitude(gpu_engine, golden_dir):
 
 def test_accuracy_guard(gpu_engine):
     """VERDICT r05 #1c: beside the f16 RANGE guard an ACCURACY guard -- at load every model's split-f16 kernels are compared with the
-    exact-fp32 ones on one deterministic probe slice (256 x 256) and the model is pinned to the exact kernels above 5e-4.  The
+    exact-fp32 ones on two deterministic probe slices (256 x 256: phantom-like, uniform noise) and the model is pinned to the exact kernels above 5e-4.  The
     Appendix-D model (head at std 8) passes with room and stays on the fast path; the same network with the head at std 30 -- whose
     split result is 1.5e-3 from the reference (test_logit_range_sweep) -- is pinned at load and then meets the 1e-3 bar; the models
     the bench runs (lung-like heads, 3 and 6 classes) stay on the fast path."""
@@ -395,6 +395,23 @@ def test_accuracy_guard(gpu_engine):
         e30 = float(np.abs(logp - ref).max())
         print(f"accuracy guard: probe at std 8 {err8:.2e} (stays split-f16), at std 30 {err30:.2e} (pinned to fp32: max|dlogp| vs the oracle {e30:.2e})")
         assert e30 < TOL
+        # heavy-tailed weights (test_forward_heavy_tailed_weights: the split kernels are 5.5e-4 .. 8.6e-4 from the reference depending on
+        # the input, profiles/r06a_precision_dist.log): whatever the guard decides, the model's result meets the bar
+        g = torch.Generator().manual_seed(5)
+        heavy = dict(base)
+        for k, v in heavy.items():
+            if k.endswith(".weight") and v.ndim == 4 and v.shape[-1] == 3 and v.shape[1] >= 64:
+                heavy[k] = torch.where(torch.rand(v.shape, generator=g) < 5e-4, v * 60.0, v)
+        xr = np.random.default_rng(8).random((2, 256, 256), dtype=np.float32)
+        heavy = uo.calibrate_head(heavy, torch.from_numpy(xr[:1, None]), 8.0)
+        gpu_engine.load_state_dict(0, heavy)
+        errh, pinned = gpu_engine.model_probe(0)
+        lab, logp = gpu_engine.forward(0, xr)
+        with torch.inference_mode():
+            refh = uo.forward(heavy, torch.from_numpy(xr[:, None])).numpy()
+        eh = float(np.abs(logp - refh).max())
+        print(f"accuracy guard, heavy-tailed weights: probe {errh:.2e} -> {'pinned to fp32' if pinned else 'stays split-f16'}; max|dlogp| vs the oracle {eh:.2e}")
+        assert eh < TOL and (pinned or errh <= 5e-4) and (not pinned or eh < 4e-4)
         # a model loaded while the engine is on the exact kernels meets the guard when the engine goes back to the split ones
         gpu_engine.set_precision("f32")
         gpu_engine.load_state_dict(0, sd30)

@@ -71,6 +71,41 @@ def test_slab_sharded_postprocessing_emulated(emu_engine):
             e.close()
 
 
+def test_slab_protocol_region_graph_adversarial_emulated(emu_engine):
+    from lungmask_amd import _native as nat
+
+    extra = [nat.Engine(0, emu_engine.L) for _ in range(2)]
+    try:
+        cases.check_slab_postprocess_diagonal_adversarial([emu_engine] + extra)
+    finally:
+        for e in extra:
+            e.close()
+
+
+def test_slab_protocol_voxel_form_emulated():
+    """LM_SLAB_GRAPH=0: the six-exchange form of the slab protocol (second labelling as voxel passes; the A/B arm of the region-graph
+    form) stays exact.  Own process: the switch is read once."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import prepost_cases as cases\n"
+            "from lungmask_amd import _native as nat\n"
+            "from lungmask_amd.build import build_emu\n"
+            "from lungmask_amd.pipeline import postprocess_slabs_in_process\n"
+            "L = nat.Library(build_emu(), allow_emulation=True)\n"
+            "engs = [nat.Engine(0, L) for _ in range(3)]\n"
+            "assert cases.check_slab_postprocess(engs, seeds=range(1)) >= 20\n"
+            "assert postprocess_slabs_in_process.last_rounds == 6\n"
+            "cases.check_slab_postprocess_diagonal_adversarial(engs, n_iter=8)\n"
+            "print('voxel form ok')\n") % (os.path.dirname(here), here)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LM_SLAB_GRAPH="0", OMP_NUM_THREADS="4"),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0 and "voxel form ok" in r.stdout, r.stdout[-2000:]
+
+
 def test_postprocessing_table_growth_paths_emulated():
     """The post-processing sizes its region / record tables from the previous volume and fetches a guessed prefix of them in the
     same read-back as the counts (post_engine.hip).  With LM_POST_SMALL_TABLES=1 every table and guess starts tiny, so the golden and
