@@ -564,6 +564,7 @@ def main():
         if bd is not None:
             dist_breakdown = {k: round(over_ranks(v), 4) for k, v in bd.items() if isinstance(v, float)}
             dist_breakdown["collectives"] = [{"name": c["name"], "bytes_per_rank": c["bytes_per_rank"], "ms": round(over_ranks(c["ms"]), 4)} for c in bd["collectives"]]
+            dist_breakdown["collectives_ms"] = round(sum(c["ms"] for c in dist_breakdown["collectives"]), 4)  # (of the per-entry maxima)
             dist_breakdown["segments_rank0"] = bd.get("segments")
             dist_breakdown["note"] = ("one extra untimed step: HIP events on the engine's stream (the stream the kernels AND the collectives are enqueued on), max over "
                                       "ranks per entry; *_ms = stream time of the stage without its collectives; host_merge_ms = wall time inside lm_slab_step "

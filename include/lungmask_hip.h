@@ -173,7 +173,7 @@ int lm_keep_largest_dev(lm_engine* e, uint8_t* mask_dev, int n, int h, int w, in
  * host, [2]=regions processed by the merge loop, [3]=regions merged, [4]=host replay in us. */
 /* ---- the same post-processing with the volume's slices spread over `world` ranks (multi-GPU pipeline) ----
  * Every rank holds a contiguous slab lab_slab_dev u8 [n][h][w] = slices [z0, z0+n) of a volume of n_total slices and
- * runs the voxel passes on its slab only; the slabs are tied together by four small exchanges (six with LM_SLAB_GRAPH=0, the voxel form of the second labelling) the CALLER performs
+ * runs the voxel passes on its slab only; the slabs are tied together by six small exchanges (four with LM_SLAB_GRAPH=1, the region-graph form of the second labelling) the CALLER performs
  * (torch.distributed all_gather over RCCL; csrc/slab_engine.hip describes each).  Protocol, identical on every rank:
  *     lm_slab_begin(...);
  *     do { len = lm_slab_pending(e);                       // int32 words this rank contributes

@@ -775,10 +775,10 @@ int model_probe(lm_engine* e, int slot) {
     md.probe_err = -1.f;
 #ifdef LM_EMU_BUILD  // the test emulator probes only when asked to (every probe is two emulated forwards), and on a small image
     static const char* const dflt = nullptr;
-    constexpr int HW = 32;
+    constexpr int HW = 32, NS = 1;  // (the noise slice only)
 #else
     static const char* const dflt = "5e-4";
-    constexpr int HW = 256;
+    constexpr int HW = 256, NS = 2;
 #endif
     const char* env = getenv("LM_ACC_GUARD");
     if (!env) env = dflt;
@@ -786,6 +786,7 @@ int model_probe(lm_engine* e, int slot) {
     if (!(thr > 0.0) || md.force_f32) return LM_OK;
     std::vector<float> x;
     probe_image(HW, HW, x);
+    if (NS == 1) x.erase(x.begin(), x.begin() + (size_t)HW * HW);
     const size_t nx = x.size(), nl = nx * md.n_classes;
     DevBuf buf;
     LM_TRY(buf.reserve((nx + 2 * nl) * sizeof(float) + nx));
@@ -798,12 +799,12 @@ int model_probe(lm_engine* e, int slot) {
     if (e->range_flag != nullptr && hipMemsetAsync(e->range_flag, 0, sizeof(unsigned), e->stream) != hipSuccess) return fail(LM_ERR_DEVICE);
     const bool prof_on = e->prof.on;
     e->prof.on = false;  // (the probe is not part of anybody's measurement)
-    int rc = forward(e, slot, xd, 2, HW, HW, lab, lp[0]);
+    int rc = forward(e, slot, xd, NS, HW, HW, lab, lp[0]);
     bool tripped = false;
     if (rc == LM_OK) rc = forward_range_check(e, slot, &tripped);  // (pins the model itself when the probe leaves the f16 range)
     if (rc == LM_OK && !tripped) {
         md.force_f32 = true;
-        rc = forward(e, slot, xd, 2, HW, HW, lab, lp[1]);
+        rc = forward(e, slot, xd, NS, HW, HW, lab, lp[1]);
         md.force_f32 = false;
     }
     e->prof.on = prof_on;

@@ -15,7 +15,9 @@
 //   step 5: [host] union -> holes = background components without a flagged atom (fill_voids.fill, utils.py:352);
 //           write kept component + holes per label in ascending label order (utils.py:353-354).
 //
-// Region-graph form (round 6, the default; LM_SLAB_GRAPH=0 is the six-exchange voxel form above, kept as the A/B and test arm): the
+// Region-graph form (round 6; LM_SLAB_GRAPH=1 -- built, exact, and NOT the default: it moves the second labelling from the devices,
+// where every rank labels 1 / world of the voxels, to the host of EVERY rank, which then walks all ranks' records and pairs: 5.3 against
+// 4.8 ms per rank at four ranks and 8.1 against 6.5 at eight, same box, profiles/r06i_slab_graph_vs_voxel_same_box.log): the
 // second labelling -- the components of the MAPPED volume -- needs no voxel pass at all, as in the single-GPU path (post_engine.hip:
 // RegionGraph).  A component of the mapped volume is a union of atoms of the FIRST labelling that are 26-adjacent and carry the same
 // mapped label: the 6-adjacency is in the boundary records (halo neighbours included), the diagonal rest inside a slab comes from
@@ -29,6 +31,7 @@
 // boundary records are per voxel and are de-duplicated after the atom -> region mapping, and the merge replay is
 // the same code as in the single-GPU path.  Every rank performs the identical host merge on identical tables.
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <numeric>
 
@@ -218,6 +221,10 @@ int unite_atoms(const SlabState& st, const std::vector<AtomTable>& t, const std:
 // labels that have one.
 int merge_regions(lm_engine* e, std::vector<uint8_t>& my_lut, std::vector<uint8_t>* keeplut = nullptr, std::vector<int>* labels = nullptr) {
     SlabState& st = e->slab;
+    static const bool timing = [] { const char* v = getenv("LM_POST_TIMING"); return v && v[0] == '1'; }();
+    const auto t_start = std::chrono::steady_clock::now();
+    auto ms_now = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+    double t_regions = 0, t_records = 0, t_replay = 0;
     std::vector<AtomTable> t;
     std::vector<int> base;
     LM_TRY(parse_atom_tables(st, t, base));
@@ -248,6 +255,7 @@ int merge_regions(lm_engine* e, std::vector<uint8_t>& my_lut, std::vector<uint8_
             lv[region[c]] = (uint8_t)t[r].lv[a];
         }
     for (int i = 0; i < R; ++i) area[i + 1] = (int)carea[roots[i]];
+    t_regions = ms_now();
     // boundary records in region ids
     size_t total_rec = 0;
     for (int r = 0; r < st.world; ++r) total_rec += (size_t)t[r].nrec;
@@ -286,59 +294,53 @@ int merge_regions(lm_engine* e, std::vector<uint8_t>& my_lut, std::vector<uint8_
     info.regions = R;
     info.boundary_records = (long long)recs.size();
     std::vector<uint8_t> lut;
+    t_records = ms_now();
     replay_merge(R, area.data(), lv.data(), recs.data(), recs.size(), st.spare, st.skip_below, lut, info);
+    t_replay = ms_now();
     my_lut.assign((size_t)t[st.rank].n + 1, 0);
     for (int a = 0; a < t[st.rank].n; ++a) my_lut[a + 1] = lut[region[base[st.rank] + a]];
     if (keeplut == nullptr) return LM_OK;
-    // ---- the second labelling on the atom graph: atoms with the same mapped label that are 26-adjacent
-    std::vector<uint8_t> mlab(G);
-    for (int g = 0; g < G; ++g) mlab[g] = lut[region[g]];
-    UnionFind uf2(G);
-    auto join = [&](int ga, int gb) {
-        if (mlab[ga] && mlab[ga] == mlab[gb]) uf2.unite(ga, gb);
+    // ---- the second labelling on the REGION graph (atoms of one region carry one mapped label and are connected): regions with the
+    // same mapped label that are 26-adjacent -- the 6-adjacency from the records the replay just used (already in region ids), the
+    // diagonal rest from the slabs' diagonal pairs and from the all-pairs face edges, both mapped atom -> region
+    UnionFind uf2(R + 1);
+    auto join = [&](int ra, int rb) {
+        if (ra != rb && lut[ra] && lut[ra] == lut[rb]) uf2.unite(ra, rb);
     };
+    for (const BoundaryRec& q : recs)
+        for (int i = 0; i < 6 && q.nb[i]; ++i) join(q.atom, q.nb[i]);
     for (int r = 0; r < st.world; ++r) {
-        for (int j = 0; j < t[r].nrec; ++j) {  // 6-adjacency (ranges were checked above)
-            const int* q = t[r].recs + 8 * (size_t)j;
-            const int ga = base[r] + q[0] - 1;
-            for (int i = 0; i < 6 && q[1 + i]; ++i) {
-                const int code = q[1 + i], id = code & ~HALO_MASK;
-                const int rr = (code & HALO_LO) ? r - 1 : ((code & HALO_HI) ? r + 1 : r);
-                join(ga, base[rr] + id - 1);
-            }
-        }
         for (int j = 0; j < t[r].ndiag; ++j) {  // diagonal-only neighbours inside the slab
             const int a = t[r].diag[2 * j], b = t[r].diag[2 * j + 1];
             if (a < 1 || a > t[r].n || b < 1 || b > t[r].n) {
                 set_error("slab: diagonal pair (%d,%d) of rank %d out of range", a, b, r);
                 return LM_ERR_INVALID;
             }
-            join(base[r] + a - 1, base[r] + b - 1);
+            join(region[base[r] + a - 1], region[base[r] + b - 1]);
         }
-        for (int j = 0; j < t[r].nedge; ++j) join(base[r] + t[r].edges[2 * j] - 1, base[r + 1] + t[r].edges[2 * j + 1] - 1);  // across the face (checked by unite_atoms)
+        for (int j = 0; j < t[r].nedge; ++j)  // across the face (ranges checked by unite_atoms)
+            join(region[base[r] + t[r].edges[2 * j] - 1], region[base[r + 1] + t[r].edges[2 * j + 1] - 1]);
     }
-    std::vector<int> cf2(G, 0x7fffffff);
-    std::vector<long long> ca2(G, 0);
+    std::vector<int> cf2(R + 1, 0x7fffffff);
+    std::vector<long long> ca2(R + 1, 0);
     long long nonzero = 0;
-    for (int r = 0; r < st.world; ++r)
-        for (int a = 0; a < t[r].n; ++a) {
-            const int g = base[r] + a;
-            if (!mlab[g]) continue;
-            const int c = uf2.find(g);
-            ca2[c] += t[r].area[a];
-            cf2[c] = std::min(cf2[c], t[r].first[a]);
-            nonzero += t[r].area[a];
-        }
+    for (int i = 1; i <= R; ++i) {
+        if (!lut[i]) continue;
+        const int c = uf2.find(i);
+        ca2[c] += area[i];
+        cf2[c] = std::min(cf2[c], cfirst[roots[i - 1]]);
+        nonzero += area[i];
+    }
     // largest area; on ties the component with the LAST first voxel (merge_components' rule, the single-GPU path's key)
     int best[256];
     for (int i = 0; i < 256; ++i) best[i] = -1;
-    for (int g = 0; g < G; ++g) {
-        if (!mlab[g] || uf2.find(g) != g) continue;
-        const int L = mlab[g], b = best[L];
-        if (b < 0 || ca2[g] > ca2[b] || (ca2[g] == ca2[b] && cf2[g] > cf2[b])) best[L] = g;
+    for (int i = 1; i <= R; ++i) {
+        if (!lut[i] || uf2.find(i) != i) continue;
+        const int L = lut[i], b = best[L];
+        if (b < 0 || ca2[i] > ca2[b] || (ca2[i] == ca2[b] && cf2[i] > cf2[b])) best[L] = i;
     }
     // utils.py:355 `np.unique(outmask_mapped)[1:]`: without a background voxel in the mapped volume the smallest LABEL is dropped
-    bool drop_smallest = G > 0 && nonzero == (long long)st.n_total * st.H * st.W;
+    bool drop_smallest = R > 0 && nonzero == (long long)st.n_total * st.H * st.W;
     labels->clear();
     for (int L = 1; L < 256; ++L)
         if (best[L] >= 0) {
@@ -351,9 +353,12 @@ int merge_regions(lm_engine* e, std::vector<uint8_t>& my_lut, std::vector<uint8_
         }
     keeplut->assign((size_t)t[st.rank].n + 1, 0);
     for (int a = 0; a < t[st.rank].n; ++a) {
-        const int g = base[st.rank] + a, L = mlab[g];
-        if (L && best[L] == uf2.find(g)) (*keeplut)[a + 1] = (uint8_t)L;
+        const int reg = region[base[st.rank] + a], L = lut[reg];
+        if (L && best[L] == uf2.find(reg)) (*keeplut)[a + 1] = (uint8_t)L;
     }
+    if (timing && st.rank == 0)
+        fprintf(stderr, "lm_slab merge (rank 0 of %d): atoms -> regions %.3f | records in region ids %.3f | merge replay %.3f | components on the region graph %.3f ms "
+                "(%d atoms, %d regions, %zu records)\n", st.world, t_regions, t_records, t_replay, ms_now(), G, R, recs.size());
     return LM_OK;
 }
 
@@ -542,7 +547,7 @@ int slab_begin(lm_engine* e, uint8_t* lab, int n, int h, int w, int rank, int wo
     st.rank = rank; st.world = world; st.n = n; st.H = h; st.W = w; st.z0 = z0; st.n_total = n_total; st.skip_below = skip_below;
     st.spare.assign(spare, spare + (spare ? n_spare : 0));
     st.lab = lab;
-    static const bool graph_ok = [] { const char* v = getenv("LM_SLAB_GRAPH"); return !(v && v[0] == '0'); }();
+    static const bool graph_ok = [] { const char* v = getenv("LM_SLAB_GRAPH"); return v && v[0] == '1'; }();
     st.graph = graph_ok;
     st.keep_ids = nullptr;
     const Dims d{n, h, w};

@@ -559,10 +559,24 @@ class LMInferer:
             raw = eng.to_device(np.ascontiguousarray(inimg_raw))
             lps = eng.reorient_dev(raw, axes, flips)
             raw.free()
+            inv = volume_io.inverse_transform(axes, flips)
             out_lps = eng.empty(lps.shape, np.uint8)
-            eng.apply_dev(0, lps, out_lps, fill_slot=self.fill_slot, batch_size=self.batch_size,
-                          volume_postprocessing=self.volume_postprocessing)
-            back = eng.reorient_dev(out_lps, *volume_io.inverse_transform(axes, flips))
+            if self.fill_slot < 0:
+                eng.apply_dev(0, lps, out_lps, fill_slot=-1, batch_size=self.batch_size, volume_postprocessing=self.volume_postprocessing)
+                back = eng.reorient_dev(out_lps, *inv)
+            else:
+                # The reference orients EACH model's result back inside _inference (mask.py:204-208) and then fuses and post-processes
+                # in the image's ORIGINAL orientation (mask.py:228-232): the 3-D post-processing is equivariant under axis
+                # permutations and flips except where raster order decides (region numbering behind the merge order and its ties,
+                # equal-area components) and in its single-slice branch (utils.py:344) -- so it must see the original axes.
+                eng.apply_dev(0, lps, out_lps, fill_slot=-1, batch_size=self.batch_size, volume_postprocessing=self.volume_postprocessing)
+                back = eng.reorient_dev(out_lps, *inv)                                     # res_l (mask.py:222)
+                eng.apply_dev(self.fill_slot, lps, out_lps, fill_slot=-1, batch_size=self.batch_size, volume_postprocessing=self.volume_postprocessing)
+                res_r = eng.reorient_dev(out_lps, *inv)                                    # res_r (mask.py:227)
+                spare = ctypes.c_int()
+                eng.L.check(eng.L.lib.lm_fuse_dev(eng.h, back.ptr, res_r.ptr, back.nbytes, ctypes.byref(spare)), "lm_fuse_dev")  # mask.py:228-230
+                eng.postprocess_dev(back, spare=[spare.value])                             # mask.py:232
+                res_r.free()
             eng.sync()
             outmask = back.download()
             for d in (lps, out_lps, back):

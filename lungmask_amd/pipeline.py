@@ -7,8 +7,7 @@ weights replicated, NO collective.  The 3-D post-processing (utils.py:272-358) s
 the whole volume; two forms:
 
 * slab-sharded (default from four ranks on): every rank post-processes its own slab and the slabs are tied
-  together by four small all-gathers of face planes / atom tables (`lm_slab_*`; round 6: the second labelling runs on the atom
-  graph inside the first table merge -- six exchanges before,
+  together by six small all-gathers of face planes / atom tables (`lm_slab_*`; four in the region-graph form, LM_SLAB_GRAPH=1,
   csrc/slab_engine.hip) -- the voxel passes scale with 1/world;
 * gathered (`sharded_post=False`, the default below four ranks, and whenever a rank has no slice): ONE all-gather of the
   uint8 256x256 label shards (64 KiB/slice), then every rank runs the identical
@@ -192,7 +191,7 @@ class ShardedPipeline:
         self.device = torch.device(device)
         self.world = dist.get_world_size() if dist is not None else 1
         self.rank = dist.get_rank() if dist is not None else 0
-        # None: by world size.  The slab protocol's fixed part (four exchanges and two host table merges; six and three before round 6) only pays from four ranks
+        # None: by world size.  The slab protocol's fixed part (six exchanges, three host table merges) only pays from four ranks
         # on -- below the crossover the redundant whole-volume pass on the gathered labels is cheaper (tools/slab_timing.py)
         # (round 5, lung-like labels of ONE 300 w-slice volume, profiles/r05d_slab_timing_lunglike.log: whole-volume pass 2.7 / 5.0 / 9.1 ms
         # at 600 / 1200 / 2400 slices against 3.7 / 4.7 / 6.5 ms per rank for the protocol at 2 / 4 / 8 ranks: the crossover is at four)
@@ -303,7 +302,7 @@ class ShardedPipeline:
                     self._all_gather(gathered, mine, f"slab_planes_round{rnd}")
             else:
                 # variable-length tables: every rank sends [length | table | padding] of ONE agreed size, so the lengths travel
-                # inside the table exchange (4 collectives per volume instead of 6; voxel form: 6 instead of 9).  The agreed capacity of round `rnd` is what
+                # inside the table exchange (6 collectives per volume instead of 9).  The agreed capacity of round `rnd` is what
                 # the previous volume needed plus a quarter -- every rank saw the same lengths, so every rank holds the same
                 # number; the first volume (and a table that outgrows the capacity, which every rank notices at the same
                 # time) exchanges the lengths first, as before.
@@ -477,7 +476,7 @@ class ShardedPipeline:
         n_r, maxc = counts[self.rank], max(counts)
         oh, ow = self.res
         if self._use_slabs(counts, n_total):
-            # ---- post-processing on the own slab; four small exchanges inside (no label all-gather at all)
+            # ---- post-processing on the own slab; six small exchanges inside (no label all-gather at all)
             mine_lab = lab_loc[:n_r]
             if self.volume_postprocessing:
                 self.postprocess_slab(mine_lab, bounds[self.rank], n_total)
@@ -604,7 +603,7 @@ def postprocess_slabs_in_process(engines, lab: np.ndarray, bounds: Sequence[int]
         assert len(set(status)) == 1, status
         if status[0] == 1:
             break
-    assert rounds in (4, 6), rounds  # four exchanges in the region-graph form (the default), six in the voxel form (LM_SLAB_GRAPH=0)
+    assert rounds in (4, 6), rounds  # six exchanges (the default), four in the region-graph form (LM_SLAB_GRAPH=1)
     postprocess_slabs_in_process.last_rounds = rounds
     out = np.concatenate([d.download() for d in slabs])
     for d in slabs:

@@ -648,7 +648,14 @@ def write_dicom(path: str, vol: Volume, keep_meta: Optional[Dict[str, str]] = No
         origin = origin + d0[:, 2] * spacing[2] * (n - 1)
         a = np.ascontiguousarray(a[::-1])
         cosz = -cosz
-    if cosz < 0.999:
+        d0 = np.column_stack([d0[:, 0], d0[:, 1], -d0[:, 2]])  # (the frames now advance the other way)
+    if cosz < 0.5:
+        #  a slice axis that lies nearer to the image plane than to its normal: the projected spacing tends to zero and the
+        # file would be geometrically meaningless -- no series a scanner produces looks like this; refuse instead of writing it
+        raise ValueError("write_dicom: the slice axis is %.1f degrees off the image plane's normal -- a multi-frame file cannot express that geometry"
+                         % np.degrees(np.arccos(max(0.0, cosz))))
+    tilted = cosz < 0.999
+    if tilted:
         # a gantry-tilted or sheared series (`read_dicom_series` takes the slice direction from the first-to-last slice position):
         # the file format cannot say so.  The reference's SimpleITK writer accepts such images, and this runs AFTER the whole
         # inference: the frames are written along the in-plane normal with the slice distance projected onto it,
@@ -658,7 +665,8 @@ def write_dicom(path: str, vol: Volume, keep_meta: Optional[Dict[str, str]] = No
         _w.warn("write_dicom: the slice axis is not perpendicular to the image plane (%.1f degrees off); a multi-frame file cannot express "
                 "that -- writing the frames along the in-plane normal with the projected spacing" % np.degrees(np.arccos(min(1.0, cosz))), RuntimeWarning)
         spacing = (spacing[0], spacing[1], spacing[2] * cosz)
-    d0 = np.column_stack([d0[:, 0], d0[:, 1], nrm])
+    if tilted or n == 1:
+        d0 = np.column_stack([d0[:, 0], d0[:, 1], nrm])  # (an essentially perpendicular series keeps the direction it came with)
     vol = Volume(a, spacing, tuple(float(v) for v in origin), d0, getattr(vol, "meta", None))
     meta = {k.lower(): v for k, v in (keep_meta or {}).items()}
     study_uid = (meta.get("0020|000d") or "").strip("\0 ") or _new_uid("study", vol.origin, a.shape)

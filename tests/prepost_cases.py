@@ -293,8 +293,9 @@ def check_postprocess_diagonal_adversarial(eng, n_iter=60):
 
 
 def check_slab_postprocess_diagonal_adversarial(engines, n_iter=24):
-    """The slab protocol's region-graph form (csrc/slab_engine.hip: the second labelling on the ATOM graph -- 6-adjacency from the
-    boundary records incl. halo neighbours, diagonal pairs inside a slab, all 26-adjacent atom pairs across a slab face): the
+    """The slab protocol in either form -- the default (second labelling as voxel passes) and, with LM_SLAB_GRAPH=1, the region-graph
+    form (csrc/slab_engine.hip: the second labelling on the region graph -- 6-adjacency from the boundary records incl. halo
+    neighbours, diagonal pairs inside a slab, all 26-adjacent atom pairs across a slab face): the
     volumes of check_postprocess_diagonal_adversarial (label noise, volumes without a background voxel, diagonal lattices) cut into
     slabs at every position, with and without a spare label, against the oracle."""
     import os
@@ -329,7 +330,7 @@ def check_slab_postprocess_diagonal_adversarial(engines, n_iter=24):
                 for b in cuts:
                     out = postprocess_slabs_in_process(engines[:world], lab, b, spare, skip)
                     assert np.array_equal(out, ref), (it, shape, kind, spare, skip, b, int((out != ref).sum()))
-                    assert postprocess_slabs_in_process.last_rounds == (6 if os.environ.get("LM_SLAB_GRAPH") == "0" else 4)
+                    assert postprocess_slabs_in_process.last_rounds == (4 if os.environ.get("LM_SLAB_GRAPH") == "1" else 6)
 
 
 def check_bbox_klc(eng):

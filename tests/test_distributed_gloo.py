@@ -89,7 +89,7 @@ def _worker(rank, world, port, n_total, outdir, mode):
     elif mode == "post8":  # BASELINE config 5's split (8 x 300 slices) through the slab protocol at emulator resolution
         lab = _lung_tubes(n_total, 32)
         pipe = ShardedPipeline(eng, resolution=(32, 32), dist=dist, device="cpu", sharded_post=True)
-        for rep in range(2):  # second volume: the table lengths travel in the headers (2 instead of 4 collectives for them)
+        for rep in range(2):  # second volume: the table lengths travel in the headers (3 instead of 6 collectives for them)
             slab = torch.from_numpy(lab[b[rank] : b[rank + 1]].copy())
             c0 = pipe.collectives
             pipe.postprocess_slab(slab, b[rank], n_total)
@@ -118,8 +118,8 @@ def _worker(rank, world, port, n_total, outdir, mode):
             bbox[:n_r] = torch.from_numpy(boxes[b[rank] : b[rank + 1]])
             np.save(os.path.join(outdir, f"asm{int(sharded)}_{rank}.npy"), pipe.assemble(n_total, 96, 80).numpy().copy())
         # the exchange protocol with a fusion-style spare label, three volumes through ONE pipeline object: the first exchanges the
-        # lengths of its two variable-size tables separately (4 collectives; three tables and 6 in the voxel form), the second carries them in
-        # the tables' headers (2), the third finds every agreed capacity too small and repeats each exchange at the exact size (4)
+        # lengths of its three variable-size tables separately (6 collectives), the second carries them in the tables' headers
+        # (3), the third finds every agreed capacity too small and repeats each exchange at the exact size (6)
         pipe = ShardedPipeline(eng, resolution=(32, 32), dist=dist, device="cpu", sharded_post=True)
         counts = []
         for rep in range(3):
@@ -192,7 +192,7 @@ def test_multi_rank_gloo_assemble_and_slab_protocol(tmp_path, world, n_total):
         got = np.concatenate([np.load(tmp_path / f"slab{rep}_{r}.npy") for r in range(world)])
         assert np.array_equal(got, expect_slab), rep
     for r in range(world):
-        assert np.load(tmp_path / f"counts{r}.npy").tolist() == [4, 2, 4], r  # (region-graph form: two variable-length tables per volume, not three)
+        assert np.load(tmp_path / f"counts{r}.npy").tolist() == [6, 3, 6], r
 
 
 def test_eight_rank_gloo_slab_protocol_on_the_config5_split(tmp_path):
@@ -210,7 +210,7 @@ def test_eight_rank_gloo_slab_protocol_on_the_config5_split(tmp_path):
         got = np.concatenate([np.load(tmp_path / f"slab{rep}_{r}.npy") for r in range(world)])
         assert got.shape == expect.shape and np.array_equal(got, expect), rep
     for r in range(world):
-        assert [int(np.load(tmp_path / f"counts{rep}_{r}.npy")[0]) for rep in range(2)] == [4, 2], r
+        assert [int(np.load(tmp_path / f"counts{rep}_{r}.npy")[0]) for rep in range(2)] == [6, 3], r
 
 
 def test_native_dist_world_of_one_and_argument_checks(emu_engine):

@@ -637,3 +637,34 @@ def test_apply_async_equals_apply(gpu_engine):
     finally:
         fused.close()
         gpu_engine.load_state_dict(0, sd3)
+
+
+def test_fused_mode_on_a_permuted_image_post_processes_in_the_original_orientation(gpu_engine):
+    """ADVICE r05 / mask.py:204-208, 228-232: the reference orients each model's result back inside _inference and fuses +
+    post-processes in the image's ORIGINAL orientation; raster order decides ties there (region numbering, equal areas) and a
+    permutation can move a singleton axis into or out of the slice position (utils.py:344).  A coronal stack (index axes x, z, y, one
+    flip) and a single axial slice stored that way: LMInferer's fused result == oracle fusion + post-processing of the two single-model results in the
+    original orientation (each of which the single-model tests pin to the oracle)."""
+    from lungmask_amd import LMInferer
+    from lungmask_amd import volume_io as vio
+
+    sd6, sd3 = uo.synthetic_state_dict(6), uo.synthetic_state_dict(3)
+    lps = po.phantom(6, 512, 512, seed=51)
+    d = np.zeros((3, 3))
+    d[0, 0], d[2, 1], d[1, 2] = 1, -1, 1  # index x -> L, index y -> I, index z -> P
+    fused = LMInferer(modelname="LTRCLobes", fillmodel="R231", state_dict=sd6, fill_state_dict=sd3, engine=gpu_engine)
+    try:
+        for arr in (lps.transpose(1, 0, 2)[:, ::-1, :].copy(), lps[:1].transpose(1, 0, 2)[:, ::-1, :].copy()):  # (the second: ONE axial slice stored as 512 coronal rows)
+            img = vio.Volume(arr, (0.7, 1.5, 0.7), (0, 0, 0), d)
+            assert vio.orientation_code(img.direction) == "LIP"
+            got = fused.apply(img)
+            single_l = LMInferer(modelname="LTRCLobes", state_dict=sd6, engine=gpu_engine)
+            res_l = single_l.apply(img).copy()
+            single_r = LMInferer(modelname="R231", state_dict=sd3, engine=gpu_engine)
+            res_r = single_r.apply(img).copy()
+            gpu_engine.load_state_dict(0, sd6)  # (the single-model inferers shared the engine's slot 0)
+            expect = po.fuse(res_l, res_r)
+            assert got.shape == arr.shape and np.array_equal(got, expect), int((got != expect).sum())
+    finally:
+        fused.close()
+        gpu_engine.load_state_dict(0, sd3)

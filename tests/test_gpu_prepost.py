@@ -1,6 +1,8 @@
 """GPU parity of the pre/post-processing kernels through the C ABI: bit-exact
 against goldens produced by the reference's own utils.py, plus differential
 tests against the CPU oracle on seeded volumes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -120,6 +122,34 @@ def test_slab_sharded_postprocessing(gpu_engine):
     finally:
         for e in extra:
             e.close()
+
+
+def test_slab_protocol_adversarial_cuts(gpu_engine):
+    """The slab protocol on diagonal / no-background / noise volumes cut at every position, three in-process ranks on the one GPU,
+    against the oracle; then the same in the region-graph form (LM_SLAB_GRAPH=1, own process: the switch is read once)."""
+    import subprocess
+    import sys
+
+    from lungmask_amd import _native as nat
+
+    extra = [nat.Engine(0, gpu_engine.L) for _ in range(2)]
+    try:
+        cases.check_slab_postprocess_diagonal_adversarial([gpu_engine] + extra, n_iter=40)
+    finally:
+        for e in extra:
+            e.close()
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import prepost_cases as cases\n"
+            "from lungmask_amd import _native as nat\n"
+            "from lungmask_amd.pipeline import postprocess_slabs_in_process\n"
+            "engs = [nat.Engine(0) for _ in range(3)]\n"
+            "assert cases.check_slab_postprocess(engs) >= 60\n"
+            "assert postprocess_slabs_in_process.last_rounds == 4\n"
+            "cases.check_slab_postprocess_diagonal_adversarial(engs, n_iter=40)\n"
+            "print('graph form ok')\n") % (os.path.dirname(here), here)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LM_SLAB_GRAPH="1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0 and "graph form ok" in r.stdout, r.stdout[-2000:]
 
 
 def test_slab_sharded_postprocessing_full_size(gpu_engine):

@@ -279,6 +279,16 @@ def test_dicom_writer_left_handed_volume_keeps_every_voxel_in_place(tmp_path):
     got = vio.load_input_image(str(tmp_path / "oblique.dcm"))
     assert np.array_equal(got.array, lab) and np.allclose(got.spacing, (1, 1, 2.0 * 0.8660254), atol=1e-5)
     assert np.allclose(np.asarray(got.direction).reshape(3, 3), np.eye(3), atol=1e-6)
+    #  a slice axis nearer to the image plane than to its normal has no meaningful projected spacing: refused, not written
+    flat = vio.Volume(lab, (1, 1, 2.0), (0, 0, 0), np.array([[1.0, 0, 0.9], [0, 1.0, 0], [0, 0, 0.43589]]))
+    with pytest.raises(ValueError, match="cannot express"):
+        vio.save_image(str(tmp_path / "flat.dcm"), flat, None)
+    assert not os.path.exists(tmp_path / "flat.dcm")
+    # ... and an essentially perpendicular series (cos > 0.999) keeps the direction it came with, untouched
+    d = np.array([[1.0, 0, 0.01], [0, 1.0, 0], [0, 0, 0.99995]])
+    vio.save_image(str(tmp_path / "straight.dcm"), vio.Volume(lab, (1, 1, 2.0), (0, 0, 0), d), None)
+    got = vio.load_input_image(str(tmp_path / "straight.dcm"))
+    assert np.array_equal(got.array, lab) and np.allclose(got.spacing, (1, 1, 2.0), atol=1e-6)
 
 
 _CONDA_PY = "/opt/conda/bin/python3.9"  # the interpreter oracle/make_golden.py runs the reference's utils.py under (scikit-image 0.18.3, imageio 2.9)
