@@ -441,7 +441,7 @@ def main():
         for slot in ([0] if fill_slot < 0 else [0, 1]):
             err, pinned = eng.model_probe(slot)
             guard["models"].append({"slot": slot, "probe_max_abs_dlogp_split_vs_exact_fp32": err, "pinned_to_fp32_by_the_guard": pinned,
-                                    "runs_on": eng.model_precision(slot)})
+                                    "runs_on": eng.model_tier(slot) if hasattr(eng, "model_tier") else eng.model_precision(slot)})
         guard["note"] = ("lm_model_load ran two deterministic 256 x 256 probe slices (phantom-like, uniform noise) through the split-f16 and the exact-fp32 kernels of each model; a model "
                          "above the limit is pinned to the exact kernels (the timed region below runs on whatever `runs_on` says)")
 

@@ -116,9 +116,17 @@ int lm_model_precision(lm_engine* e, int slot);
  * model and pins it to the exact-fp32 kernels -- with a notice on stderr -- when max |delta log-prob| exceeds the limit (environment
  * LM_ACC_GUARD, default 5e-4: half of the 1e-3 of the reference's fp32 result the engine is held to; "0" disables the probe).  A
  * checkpoint with a logit range or weight tails beyond what the split arithmetic resolves therefore cannot silently sit outside the
- * tolerance.  *err_out = the probe's max |delta log-prob| (< 0: no probe was run -- guard off, or the f16 range guard tripped on the
- * probe and pinned the model first); returns 1 when the probe pinned the model, 0 when not, < 0 on error. */
+ * tolerance.  Between the two there are middle tiers: a model above the limit is probed again with the 3x3 convs split along K so that
+ * no fp32 accumulator chain runs over more than 4608, then 2304, then 1152 products (the chain's roundings are where the split
+ * arithmetic's error comes from; parts are work items of their own, added in a fixed order; +1 % / +4 % / +12 % forward time instead
+ * of the exact kernels' 4x) and runs on the first form that is within the limit (lm_model_precision still says 1: split-f16;
+ * lm_model_chain_limit says which).
+ * *err_out = max |delta log-prob| of the probe of the form the model runs on (< 0: no probe was run -- guard off, or the f16 range
+ * guard tripped on the probe and pinned the model first); returns 0 fast split-f16 form, 2 a split-K form, 1 pinned to the
+ * exact-fp32 kernels by the probe, < 0 on error.  LM_H3_KSPLIT_K=<products> puts every model on that split-K form (A/B and test hook). */
 int lm_model_probe_error(lm_engine* e, int slot, float* err_out);
+/* products per accumulator chain of the model's 3x3 convs: 0 = not split (the fast form), else the limit the accuracy guard chose. */
+int lm_model_chain_limit(lm_engine* e, int slot);
 
 /* ---- network forward (mask.py:178-186: model(mbt) + torch.max(pred,1)[1]) ------ */
 /* x_dev: f32 [b][h][w] (h, w multiples of 16).  labels_dev: u8 [b][h][w] or NULL.

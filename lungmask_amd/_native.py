@@ -83,6 +83,7 @@ class Library:
             L.lm_model_precision.argtypes = [C.c_void_p, C.c_int]
         if hasattr(L, "lm_model_probe_error"):
             L.lm_model_probe_error.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+            L.lm_model_chain_limit.argtypes = [C.c_void_p, C.c_int]
         L.lm_forward_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.lm_set_precision.argtypes = [C.c_void_p, C.c_int]
         L.lm_set_streams.argtypes = [C.c_void_p, C.c_int]
@@ -279,6 +280,16 @@ class Engine:
         rc = self.L.lib.lm_model_probe_error(self.h, slot, C.byref(err))
         self.L.check(min(rc, 0), "lm_model_probe_error")
         return (None if err.value < 0 else float(err.value)), rc == 1
+
+    def model_tier(self, slot: int) -> str:
+        """'split_f16' (fast form), 'split_f16_chain<K>' (the accuracy guard's middle tiers: 3x3 convs split along K, no accumulator chain
+        over K products) or 'f32'."""
+        err = C.c_float()
+        rc = self.L.lib.lm_model_probe_error(self.h, slot, C.byref(err))
+        self.L.check(min(rc, 0), "lm_model_probe_error")
+        if self.model_precision(slot) == "f32":
+            return "f32"
+        return f"split_f16_chain{self.L.lib.lm_model_chain_limit(self.h, slot)}" if rc == 2 else "split_f16"
 
     def set_precision(self, mode):
         """'f32' / 0: exact fp32 matrix ops;  'split_f16' / 1: 3-product split-f16."""

@@ -157,9 +157,14 @@ int lm_model_load(lm_engine* e, int slot, const lm_tensor* tensors, int n_tensor
 int lm_model_probe_error(lm_engine* e, int slot, float* err_out) {
     if (!e || slot < 0 || slot >= 4 || !e->models[slot].loaded || !err_out) return LM_ERR_NOMODEL;
     *err_out = e->models[slot].probe_err;
-    return e->models[slot].acc_pinned ? 1 : 0;
+    return e->models[slot].acc_pinned ? 1 : (e->models[slot].chain_k > 0 ? 2 : 0);
 }
 void* lm_engine_stream(lm_engine* e) { return e ? reinterpret_cast<void*>(e->stream) : nullptr; }
+
+int lm_model_chain_limit(lm_engine* e, int slot) {
+    if (!e || slot < 0 || slot >= 4 || !e->models[slot].loaded) return LM_ERR_NOMODEL;
+    return e->models[slot].chain_k;
+}
 
 int lm_model_classes(lm_engine* e, int slot) {
     if (!e || slot < 0 || slot >= 4 || !e->models[slot].loaded) return LM_ERR_NOMODEL;

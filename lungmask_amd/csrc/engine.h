@@ -61,6 +61,16 @@ struct ConvLayer {
     std::vector<float> h_fold_s, h_row_pow2;
 };
 
+// accumulator-chain limits the accuracy guard walks through (products per chain; 0 = no split: up to 9 216).  Measured on the 300-slice
+// two-lane forward (profiles/r06j_ksplit_ab.log): +1 % / +4 % / +12 % time, heavy-tailed weights' rms error x 0.80 / 0.63 / 0.52
+#ifdef LM_EMU_BUILD  // (the test emulator: every tier is another emulated forward)
+constexpr int kChainTiers[] = {0, 1152};
+constexpr int kNChainTiers = 2;
+#else
+constexpr int kChainTiers[] = {0, 4608, 2304, 1152};
+constexpr int kNChainTiers = 4;
+#endif
+
 struct Model {
     bool loaded = false;
     int n_classes = 0;
@@ -81,6 +91,10 @@ struct Model {
     // accuracy guard (nn_engine.hip: model_probe): split-f16 against exact-fp32 on one probe slice at load time
     bool probed = false, acc_pinned = false;
     float probe_err = -1.f;  // max |delta log-prob| of the probe; < 0: not probed (guard off, fp32 engine, or the range guard tripped first)
+    // the guard's middle tiers: split-f16 with the 3x3 convs split along K so that no accumulator chain runs over chain_k products
+    // (0: the fast form, one chain per output); probe_err is the chosen form's, probe_err_fast the single-chain form's
+    int chain_k = 0;
+    float probe_err_fast = -1.f;
     void release();
 };
 

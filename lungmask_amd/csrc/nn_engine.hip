@@ -64,7 +64,8 @@ void Model::release() {
     loaded = false;
     force_f32 = false;
     probed = acc_pinned = false;
-    probe_err = -1.f;
+    chain_k = 0;
+    probe_err = probe_err_fast = -1.f;
 }
 
 // ------------------------------------------------------------------------------ profiler
@@ -462,6 +463,7 @@ struct Fwd {
     bool head_fused = false;  // set by conv() when the head ran inside the last conv's epilogue
     NNWorkspace* ws = nullptr;
     int abl = 0;              // LM_LAB_HOOKS builds only: kernels left out by tools/bw_tail_ablation.py
+    int ksplit_k = 0;         // > 0: split-K of the 3x3 convs so that no accumulator chain runs over more than this many products
 
     int conv(const ConvLayer& L, const float* in, int in_cs, int in_co, int H, int W, float* out, int out_cs, int out_co,
              float* pool = nullptr, int pool_cs = 0, int pool_co = 0, const HeadParams* head = nullptr, const float* fc_x = nullptr,
@@ -547,6 +549,15 @@ struct Fwd {
                 q.head_C = head->C;
                 head_fused = true;
             }
+            if (L.taps == 9 && ksplit_k > 0 && ws != nullptr && q.head_labels == nullptr && q.fc_x == nullptr) {
+                // the "precise" tier of the split-f16 path: no accumulator chain over more than ksplit_k products (nn_kernels_h3.hip: KS)
+                const int S = conv3x3_h3_ksplit(q, ksplit_k);
+                if (S > 1) {
+                    LM_TRY(ws->kpart.reserve((size_t)S * B * H * W * L.cout * 4));
+                    q.ksplit = S;
+                    q.kpart = ws->kpart.as<float>();
+                }
+            }
             err = (L.taps == 9) ? launch_conv3x3_h3(q, st) : launch_conv1x1_h3(q, st);
         } else {
             err = (L.taps == 9) ? launch_conv3x3(p, st) : launch_conv1x1(p, st);
@@ -601,6 +612,10 @@ int forward(lm_engine* e, int slot, const float* x, int B, int H, int W, uint8_t
     f.zeros = md.zeros_h3;
     f.ones = md.ones_h3;
     f.ws = &ws;
+    {   // LM_H3_KSPLIT_K: the precise tier's chain limit for EVERY model (A/B and test hook; 0 / unset: only models the guard put there)
+        static const int env_k = [] { const char* v = getenv("LM_H3_KSPLIT_K"); return v ? atoi(v) : 0; }();
+        f.ksplit_k = h3 ? (env_k > 0 ? env_k : md.chain_k) : 0;
+    }
     if (h3 && !e->zero_page) {
         void* zp = nullptr;
         LM_HIP(hipMalloc(&zp, 512));
@@ -794,39 +809,62 @@ int model_probe(lm_engine* e, int slot) {
     float* lp[2] = {xd + nx, xd + nx + nl};
     uint8_t* lab = reinterpret_cast<uint8_t*>(xd + nx + 2 * nl);  // (the production form of the last conv: head fused into its epilogue)
     std::vector<float> h[2] = {std::vector<float>(nl), std::vector<float>(nl)};
-    auto fail = [&](int rc) { buf.release(); return rc; };
+    const bool prof_on = e->prof.on;
+    auto fail = [&](int rc) {
+        e->prof.on = prof_on;
+        buf.release();
+        return rc;
+    };
     if (hipMemcpyAsync(xd, x.data(), nx * sizeof(float), hipMemcpyHostToDevice, e->stream) != hipSuccess) return fail(LM_ERR_DEVICE);
     if (e->range_flag != nullptr && hipMemsetAsync(e->range_flag, 0, sizeof(unsigned), e->stream) != hipSuccess) return fail(LM_ERR_DEVICE);
-    const bool prof_on = e->prof.on;
     e->prof.on = false;  // (the probe is not part of anybody's measurement)
-    int rc = forward(e, slot, xd, NS, HW, HW, lab, lp[0]);
-    bool tripped = false;
-    if (rc == LM_OK) rc = forward_range_check(e, slot, &tripped);  // (pins the model itself when the probe leaves the f16 range)
-    if (rc == LM_OK && !tripped) {
-        md.force_f32 = true;
-        rc = forward(e, slot, xd, NS, HW, HW, lab, lp[1]);
-        md.force_f32 = false;
+    // the exact-fp32 kernels' result, once
+    md.force_f32 = true;
+    int rc = forward(e, slot, xd, NS, HW, HW, lab, lp[1]);
+    md.force_f32 = false;
+    if (rc != LM_OK) return fail(rc);
+    if (hipMemcpyAsync(h[1].data(), lp[1], nl * sizeof(float), hipMemcpyDeviceToHost, e->stream) != hipSuccess) return fail(LM_ERR_DEVICE);
+    // The split-f16 kernels, from the fast form to ever shorter accumulator chains (kChainTiers: 0 = one chain per output, then the
+    // 3x3 convs split along K so that no chain runs over more than that many products -- nn_kernels_h3.hip: KS): the model runs on
+    // the first form that is within the limit, and on the exact-fp32 kernels when none is.
+    float first_err = -1.f;
+    for (int tier = 0; tier < kNChainTiers; ++tier) {
+        md.chain_k = kChainTiers[tier];
+        rc = forward(e, slot, xd, NS, HW, HW, lab, lp[0]);
+        bool tripped = false;
+        if (rc == LM_OK) rc = forward_range_check(e, slot, &tripped);  // (pins the model itself when the probe leaves the f16 range)
+        if (rc != LM_OK || tripped) {
+            md.chain_k = 0;
+            return fail(rc);
+        }
+        if (hipMemcpyAsync(h[0].data(), lp[0], nl * sizeof(float), hipMemcpyDeviceToHost, e->stream) != hipSuccess) return fail(LM_ERR_DEVICE);
+        if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(LM_ERR_DEVICE);
+        float err = 0.f;
+        for (size_t i = 0; i < nl; ++i) {
+            const float d = std::fabs(h[0][i] - h[1][i]);
+            err = (d > err || !(d == d)) ? (d == d ? d : INFINITY) : err;
+        }
+        md.probe_err = err;
+        if (tier == 0) first_err = md.probe_err_fast = err;
+        if ((double)err <= thr) {
+            if (tier > 0)
+                fprintf(stderr,
+                        "lungmask_hip: model slot %d: the split-f16 kernels are %.2e from the exact-fp32 kernels on the probe slices (max |delta log-prob|, "
+                        "limit %.1e); with no accumulator chain over %d products (3x3 convs split along K) %.2e: its forward passes run on that form\n",
+                        slot, (double)first_err, thr, md.chain_k, (double)err);
+            (void)fail(LM_OK);
+            return LM_OK;
+        }
     }
-    e->prof.on = prof_on;
-    if (rc != LM_OK || tripped) return fail(rc);
-    for (int k = 0; k < 2; ++k)
-        if (hipMemcpyAsync(h[k].data(), lp[k], nl * sizeof(float), hipMemcpyDeviceToHost, e->stream) != hipSuccess) return fail(LM_ERR_DEVICE);
-    if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(LM_ERR_DEVICE);
-    buf.release();
-    float err = 0.f;
-    for (size_t i = 0; i < nl; ++i) {
-        const float d = std::fabs(h[0][i] - h[1][i]);
-        err = (d > err || !(d == d)) ? (d == d ? d : INFINITY) : err;
-    }
-    md.probe_err = err;
-    if ((double)err > thr) {
-        md.force_f32 = true;
-        md.acc_pinned = true;
-        fprintf(stderr,
-                "lungmask_hip: model slot %d: the split-f16 kernels are %.2e from the exact-fp32 kernels on the probe slices (max |delta log-prob|, "
-                "limit %.1e): its forward passes run on the exact-fp32 matrix kernels (about 4x slower, same results as the reference)\n",
-                slot, (double)err, thr);
-    }
+    (void)fail(LM_OK);
+    md.chain_k = 0;
+    md.force_f32 = true;
+    md.acc_pinned = true;
+    fprintf(stderr,
+            "lungmask_hip: model slot %d: the split-f16 kernels are %.2e from the exact-fp32 kernels on the probe slices (max |delta log-prob|, limit %.1e; %.2e "
+            "with the shortest accumulator chains): its forward passes run on the exact-fp32 matrix kernels (about 4x slower, same results as the "
+            "reference)\n",
+            slot, (double)first_err, thr, (double)md.probe_err);
     return LM_OK;
 }
 

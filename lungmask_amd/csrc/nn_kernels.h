@@ -103,6 +103,9 @@ struct ConvParamsH3 {
 };
 // the K split launch_conv1x1_h3 can use for this shape (1: none) -- the engine sizes kpart with it
 int conv1x1_h3_ksplit(const ConvParamsH3& p);
+// the K split of a 3x3 launch whose accumulator chains may not run over more than max_k products (the accuracy guard's "precise"
+// tier; 1: none): set ConvParamsH3::ksplit to it and kpart to ksplit * B * H * W * Cout floats
+int conv3x3_h3_ksplit(const ConvParamsH3& p, int max_k);
 // whether launch_conv3x3_h3 can take the first layer into its loader for this shape (else run launch_first_conv_h3 first)
 bool conv3x3_h3_can_fuse_first(const ConvParamsH3& p);
 // LM_H3_FOLD_SCALE = 1: the BatchNorm SCALE s = 2^e * m (|m| in [1, 2), per channel) of a Conv -> ReLU -> BN layer leaves the

@@ -405,9 +405,17 @@ constexpr int FC_TASKS = 18 * 34 * 2;
 
 }  // namespace
 
-template <int TAPS, bool G16, int HEAD = 0, int PROD = 0>
+// KS (3x3 form): the split-K instantiation -- ConvParamsH3::ksplit parts per output tile, every part a work item of its own that sums
+// Cin / ksplit input channels in a chain that starts at zero and leaves its raw fp32 accumulators in kpart[ks];
+// splitk_reduce3_h3_kernel adds the parts in index order and runs the conv's epilogue.  The accumulator chain is what the split-f16
+// arithmetic's error comes from (3 K / 16 roundings at a magnitude that grows along the chain: the error of a layer goes with
+// K / sqrt(parts)); this is the "precise" tier of the accuracy guard (nn_engine.hip), a separate instantiation so that the 17
+// launches of the fast tier do not carry a line of it.
+template <int TAPS, bool G16, int HEAD = 0, int PROD = 0, bool KS = false>
 __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptiles, int n_items, int xcd_order) {
     using SM = H3WSmem<TAPS, G16>;
+    static_assert(!KS || (TAPS == 9 && HEAD == 0 && PROD == 0), "the split-K instantiation is the plain 3x3 form");
+    constexpr bool KSPLIT = TAPS == 1 || KS;  // instantiations that can run with ConvParamsH3::ksplit > 1
     static_assert(PROD == 0 || (TAPS == 9 && !G16 && HEAD == 0), "the loader-side producers belong to the 32-wide 3x3 form");
     constexpr int HALO = SM::HALO, PW = SM::PW, TWW = SM::TWW, NW = SM::NW, ROWB = PW * 64, NTSTEP = SM::NTSTEP;
     // Bank swizzle of the activation tile: 16-byte slot ^= (halo column >> ASWZ) & 3.  A ds_read_b128 lane group of 16
@@ -479,7 +487,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                                     : lm_make_rsrc(p.in + (size_t)p.in_coff * 4, (size_t)p.B * slice_bytes - (size_t)p.in_coff * 4);
     const lm_rsrc rsrcW = lm_make_rsrc(p.w, (size_t)TAPS * p.Cout * p.Cin * 4);
     const int tiles_x = p.W / TWW;
-    const int nchunks = p.Cin / KC / ((TAPS == 1 && p.ksplit > 1) ? p.ksplit : 1);  // per item; even (checked by the launcher)
+    const int nchunks = p.Cin / KC / ((KSPLIT && p.ksplit > 1) ? p.ksplit : 1);  // per item; even (checked by the launcher)
     // Conv -> ReLU -> BatchNorm for every 3x3 conv of the network, bias only for the decoder's 1x1 convs (resunet.py:93-105,
     // :131-133): a property of the instantiation, not a run-time select per value (the launcher sends anything else to the
     // simple kernel)
@@ -497,10 +505,10 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
     // every tile count of this network is a power of two: shifts instead of integer divisions on the item-switch path
     const bool pow2 = ((n_ct & (n_ct - 1)) | (tiles_x & (tiles_x - 1)) | (tiles_y & (tiles_y - 1))) == 0;
     const int sh_ct = 31 - __clz(n_ct), sh_tx = 31 - __clz(tiles_x), sh_ty = 31 - __clz(tiles_y);
-    // Split-K (1x1 form only, ConvParamsH3::ksplit > 1): the cout-tile index also counts the K split -- item (ks, ct, pt) sums input
+    // Split-K (the 1x1 form and the KS instantiation of the 3x3 form, ConvParamsH3::ksplit > 1): the cout-tile index also counts the K split -- item (ks, ct, pt) sums input
     // channels [ks, ks + 1) * Cin / ksplit and leaves its raw fp32 accumulators in kpart[ks]; splitk_reduce_h3_kernel adds the parts
     // in fixed order.  kc = first input channel of the item's range.
-    const int ksplit = (TAPS == 1 && p.ksplit > 1) ? p.ksplit : 1;
+    const int ksplit = (KSPLIT && p.ksplit > 1) ? p.ksplit : 1;
     auto decode = [&](int it, int& b, int& y0, int& x0, int& n0, int& kc) -> bool {
         int ct, pt;
         if (xcd_order) {
@@ -512,7 +520,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
             pt = it - ct * n_ptiles;
         }
         kc = 0;
-        if (TAPS == 1 && ksplit > 1) {  // (cout-tile-major order only: the launcher sees to it)
+        if (KSPLIT && ksplit > 1) {  // (cout-tile-major order only: the launcher sees to it)
             const int ks = ct / n_ct;
             ct -= ks * n_ct;
             kc = ks * (p.Cin / ksplit);
@@ -875,7 +883,8 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
         lm_h16x8 f[8], g[8];  // two fragment sets: whi0 whi1 wlo0 wlo1 a0hi a0lo a1hi a1lo
         bool abl_r = false;   // lab ablation (constant false in the product)
         if constexpr (TAPS == 9) {
-            set_dma(false, b, n0, KC, 1, true, -1);  // chunk 1 -> buffer 1, issued from the slots of chunk 0
+            const int kb0 = KS ? kc0 : 0, nkb0 = KS ? nkc0 : 0;  // first input channel of this / the next item's K range (0 without the split)
+            set_dma(false, b, n0, kb0 + KC, 1, true, -1);  // chunk 1 -> buffer 1, issued from the slots of chunk 0
             H3P_READS(f, buf0, 0, 0);
             for (int ci = 0; ci < nchunks; ci += 2) {
                 abl_r = LM_ABL_READS(ci);
@@ -886,8 +895,8 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                 lm_barrier_dma();  // everyone has read buffer 0 for the last time; chunk ci + 1 is complete in buffer 1
                 LM_TRACE_MARK(1);
                 H3P_READS(g, buf1, 0, 0);
-                if (ci + 2 < nchunks) set_dma(false, b, n0, (ci + 2) * KC, 0, true, -1);
-                else set_dma(true, nb, nn0, 0, 0, have_next, epar ^ 1);  // the next item's chunk 0 + epilogue constants
+                if (ci + 2 < nchunks) set_dma(false, b, n0, kb0 + (ci + 2) * KC, 0, true, -1);
+                else set_dma(true, nb, nn0, nkb0, 0, have_next, epar ^ 1);  // the next item's chunk 0 + epilogue constants
                 H3P_MFMAS(f, 0);
                 // ---- odd chunk ci + 1 (buffer 1), fragments start in g
                 H3P_CHUNK_STEPS(g, f, buf1);
@@ -897,7 +906,7 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                 LM_TRACE_MARK(1);
                 if (ci + 2 < nchunks) {
                     H3P_READS(f, buf0, 0, 0);
-                    set_dma(false, b, n0, (ci + 3) * KC, 1, true, -1);
+                    set_dma(false, b, n0, kb0 + (ci + 3) * KC, 1, true, -1);
                 } else {
                     set_dma(false, b, n0, 0, 1, false, -1);  // buffer 1 becomes the epilogue's staging area
                 }
@@ -939,8 +948,8 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
             const int Hp = p.H >> 1, Wp = p.W >> 1;
             const char* ep = reinterpret_cast<const char*>(&epi[epar][0][0]);
             bool part_done = false;
-            if constexpr (TAPS == 1) {
-                if (ksplit > 1) {
+            if constexpr (KSPLIT) {
+                if (KS || ksplit > 1) {
                     // ---- split-K: this item's raw accumulators -> kpart[ks][slice][pixel][cout] (fp32, dense), 16 bytes per lane and
                     // 4-channel quad; scale, bias and the split happen in the reduction
                     const int ks = kc0 / (p.Cin / ksplit);
@@ -960,7 +969,8 @@ __global__ __launch_bounds__(512) void conv_igemm_h3p(ConvParamsH3 p, int n_ptil
                     part_done = true;
                 }
             }
-            if (part_done) {
+            if constexpr (KS) {  // (nothing but the partial sums leaves this instantiation)
+            } else if (part_done) {
             } else if constexpr (HEAD != 0) {
                 // ---- fused head: this item holds ALL 64 channels of its pixels (n0 == 0).  Per pixel the two lanes kb = 0/1
                 // own channels 8q + 4kb + k (q = mg, k = 0..3).  The head is evaluated on the fp32 values themselves -- the last
@@ -1328,13 +1338,16 @@ static hipError_t launch_conv_h3_t(const ConvParamsH3& p, hipStream_t stream) {
             if (p.fc_x) pd.fc_x = p.fc_x + (size_t)b0 * p.H * p.W;
             const int n_ptiles = g16 ? ((p.H + TH - 1) / TH) * ((pd.B + 1) / 2) : (p.W / 32) * ((p.H + TH - 1) / TH) * pd.B;
             const int n_ct = p.Cout / TN;
-            const int ks = (TAPS == 1 && p.ksplit > 1) ? p.ksplit : 1;  // split-K items: cout-tile-major order, ks outermost
+            const int ks = p.ksplit > 1 ? p.ksplit : 1;  // split-K items: cout-tile-major order, ks outermost
             const int xcd_order = ks > 1 ? 0 : (order_env >= 0 ? order_env : (n_ct >= 2 && n_ptiles >= 64 ? 1 : 0));
             const int n_items = xcd_order ? 8 * ((n_ptiles + 7) / 8) * n_ct : n_ptiles * n_ct * ks;
             // LM_H3_GRID: lab hook, caps the number of persistent workgroups
             static const int grid_cap = [] { const char* e = getenv("LM_H3_GRID"); return e ? atoi(e) : 0; }();
             const unsigned blocks = (unsigned)std::min(n_items, grid_cap > 0 ? std::min(grid_cap, n_cu) : n_cu);
-            if (g16)
+            if (TAPS == 9 && ks > 1) {  // the split-K instantiation (launch_conv3x3_h3 has checked the shape)
+                if (g16) LM_LAUNCH((conv_igemm_h3p<9, true, 0, 0, true>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
+                else LM_LAUNCH((conv_igemm_h3p<9, false, 0, 0, true>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
+            } else if (g16)
                 LM_LAUNCH((conv_igemm_h3p<TAPS, true>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
             else if (TAPS == 9 && pd.head_labels != nullptr && pd.head_logp != nullptr)
                 LM_LAUNCH((conv_igemm_h3p<9, false, 2>), dim3(blocks), dim3(512), 0, stream, pd, n_ptiles, n_items, xcd_order);
@@ -1365,12 +1378,103 @@ bool conv3x3_h3_can_fuse_first(const ConvParamsH3& p) {
     return allow && p.Cin == 64 && p.W % 32 == 0 && p.head_labels == nullptr && h3_persistent_ok(p, 9);
 }
 
+// Reduction of a split-K 3x3 conv (the KS instantiation): parts added in index order, then the conv's epilogue -- acc * 2^-k + (bias -
+// the border correction of a deferred-shift input), ReLU, BatchNorm scale / shift (ones / zeros when the consumers carry them), the
+// hi / lo split, the f16 range guard, and the 2 x 2 average pool of the encoder's second convs.  POOL: thread = (2 x 2 pixel block,
+// 8-channel group), else (pixel, group).
+template <bool POOL>
+__global__ __launch_bounds__(256) void splitk_reduce3_h3_kernel(ConvParamsH3 p) {
+    const size_t G = (size_t)p.Cout >> 3;
+    const int Wq = POOL ? p.W >> 1 : p.W, Hq = POOL ? p.H >> 1 : p.H;
+    const size_t nq = (size_t)p.B * Hq * Wq, e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nq * G) return;
+    const size_t q = e / G;
+    const int g = (int)(e - q * G);
+    const int xq = (int)(q % Wq), yq = (int)((q / Wq) % Hq), b = (int)(q / ((size_t)Wq * Hq));
+    const size_t npix = (size_t)p.B * p.H * p.W;
+    float bias[8], sc[8], sh[8], pl[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        bias[k] = p.bias[8 * g + k];
+        sc[k] = p.bn_s[8 * g + k];
+        sh[k] = p.bn_t[8 * g + k];
+        pl[k] = 0.f;
+    }
+    unsigned gmax = 0u;
+    constexpr int NP = POOL ? 4 : 1;
+    float vv[NP][8];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int y = POOL ? 2 * yq + (i & 1) : yq, x = POOL ? 2 * xq + (i >> 1) : xq;  // (rows first: the pool's summation order below)
+        const size_t pix = ((size_t)b * p.H + y) * p.W + x;
+        float a[8];
+        for (int s = 0; s < p.ksplit; ++s) {
+            const float4* src = reinterpret_cast<const float4*>(p.kpart + ((size_t)s * npix + pix) * p.Cout + 8 * g);
+            const float4 v0 = src[0], v1 = src[1];
+            if (s == 0) {
+                a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w; a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
+            } else {
+                a[0] += v0.x; a[1] += v0.y; a[2] += v0.z; a[3] += v0.w; a[4] += v1.x; a[5] += v1.y; a[6] += v1.z; a[7] += v1.w;
+            }
+        }
+        const int mask = (y == 0 ? 1 : 0) | (y == p.H - 1 ? 2 : 0) | (x == 0 ? 4 : 0) | (x == p.W - 1 ? 8 : 0);
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float bb = bias[k];
+            if (p.border_corr != nullptr && mask) bb -= p.border_corr[(size_t)mask * p.Cout + 8 * g + k];
+            v[k] = fmaf(fmaxf(fmaf(a[k], p.acc_scale, bb), 0.f), sc[k], sh[k]);
+            vv[i][k] = v[k];
+        }
+        uint2 h0, l0, h1, l1;
+        lm_split4(v[0], v[1], v[2], v[3], &h0, &l0);
+        lm_split4(v[4], v[5], v[6], v[7], &h1, &l1);
+        gmax = lm_pk_absmax_u16(lm_pk_absmax_u16(lm_pk_absmax_u16(lm_pk_absmax_u16(gmax, h0.x), h0.y), h1.x), h1.y);
+        char* dst = p.out + (pix * p.out_cstride + p.out_coff) * 4 + (size_t)g * 32;
+        *reinterpret_cast<uint4*>(dst) = uint4{h0.x, h0.y, h1.x, h1.y};
+        *reinterpret_cast<uint4*>(dst + 16) = uint4{l0.x, l0.y, l1.x, l1.y};
+    }
+    if constexpr (POOL) {  // avg_pool2d(2): rows y, y + 1 summed first, then x + 1 (the persistent kernel's order)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pl[k] = 0.25f * ((vv[0][k] + vv[1][k]) + (vv[2][k] + vv[3][k]));
+        uint2 h0, l0, h1, l1;
+        lm_split4(pl[0], pl[1], pl[2], pl[3], &h0, &l0);
+        lm_split4(pl[4], pl[5], pl[6], pl[7], &h1, &l1);
+        char* dst = p.pool + ((((size_t)b * Hq + yq) * Wq + xq) * p.pool_cstride + p.pool_coff) * 4 + (size_t)g * 32;
+        *reinterpret_cast<uint4*>(dst) = uint4{h0.x, h0.y, h1.x, h1.y};
+        *reinterpret_cast<uint4*>(dst + 16) = uint4{l0.x, l0.y, l1.x, l1.y};
+    }
+    if (p.range_flag != nullptr && lm_pk_out_of_f16_guard(gmax)) atomicOr(p.range_flag, 1u);
+}
+
+// The K split launch_conv3x3_h3 uses for this shape when no accumulator chain may run over more than max_k = 9 * channels products
+// (1: none; the engine sizes kpart with it): parts of an even number (>= 2) of 16-channel chunks, plain 3x3 launches on the
+// persistent kernel only (no fused head / first layer), the whole batch in one launch.
+int conv3x3_h3_ksplit(const ConvParamsH3& p, int max_k) {
+    if (max_k <= 0 || p.head_labels != nullptr || p.fc_x != nullptr || p.bn_s == nullptr || p.bn_t == nullptr || !h3_persistent_ok(p, 9)) return 1;
+    if ((size_t)p.B * p.H * p.W * p.in_cstride * 4 >= 0x7fffffffull) return 1;  // (a launch cut into sub-batches keeps the single chain)
+    int S = 1;
+    while (9 * (p.Cin / S) > max_k && (p.Cin / KC) % (2 * S * 2) == 0 && p.Cin / KC / (2 * S) >= 2 && S < 16) S *= 2;
+    return S;
+}
+
 hipError_t launch_conv3x3_h3(const ConvParamsH3& p, hipStream_t stream) {
     if (p.fc_x != nullptr && (!conv3x3_h3_can_fuse_first(p) || !p.fc_c)) return hipErrorInvalidValue;
     if (p.head_labels != nullptr && (!conv3x3_h3_can_fuse_head(p) || p.head_C < 1 || p.head_C > kMaxClasses || !p.head_w || !p.head_b))
         return hipErrorInvalidValue;
     if (p.head_logp != nullptr && p.head_labels == nullptr) return hipErrorInvalidValue;
-    return launch_conv_h3_t<9>(p, stream);
+    if (p.ksplit <= 1) return launch_conv_h3_t<9>(p, stream);
+    if (p.kpart == nullptr || conv3x3_h3_ksplit(p, 9 * p.Cin / p.ksplit) != p.ksplit || (p.pool != nullptr && ((p.H | p.W) & 1))) return hipErrorInvalidValue;
+    const hipError_t err = launch_conv_h3_t<9>(p, stream);
+    if (err != hipSuccess) return err;
+    if (p.pool != nullptr) {
+        const size_t n = (size_t)p.B * (p.H / 2) * (p.W / 2) * (p.Cout >> 3);
+        LM_LAUNCH((splitk_reduce3_h3_kernel<true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p);
+    } else {
+        const size_t n = (size_t)p.B * p.H * p.W * (p.Cout >> 3);
+        LM_LAUNCH((splitk_reduce3_h3_kernel<false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p);
+    }
+    return hipGetLastError();
 }
 // Reduction of a split-K 1x1 conv: thread = (pixel, 8-channel group); parts added in index order, then the conv epilogue of the 1x1
 // form (acc * 2^-k + bias, no ReLU / BatchNorm), the hi / lo split and the f16 range guard.

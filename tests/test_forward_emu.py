@@ -241,3 +241,38 @@ def wide_batchnorm_heavy_tail_state_dict(n_classes=3, seed=9, decades=3.0, outli
             mask = torch.rand(v.shape, generator=g) < frac
             sd[k] = torch.where(mask, v * outlier, v)
     return sd
+
+
+def test_split_k_3x3_instantiation_emulated(golden_dir):
+    """The accuracy guard's middle tier (nn_kernels_h3.hip: the KS instantiation of the persistent 3x3 kernel + splitk_reduce3_h3_kernel):
+    LM_H3_KSPLIT_K=576 cuts every accumulator chain at 576 products, which at 32 x 32 puts the K = 1152 layers of the two persistent
+    geometries (32-wide: up_path.3's first conv; 16-wide: down_path.1's second conv, with its pooled output) on the split-K path:
+    the result meets the reference golden, and differs from the single-chain form in the last bits only.  Own process (the hook is
+    read once)."""
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys, os, numpy as np; sys.path.insert(0, %r)\n"
+            "from lungmask_amd import _native as nat\n"
+            "from lungmask_amd.build import build_emu\n"
+            "from oracle import unet_oracle as uo\n"
+            "g = np.load(os.path.join(%r, 'unet_c3.npz'))\n"
+            "eng = nat.Engine(0, nat.Library(build_emu(), allow_emulation=True))\n"
+            "eng.load_state_dict(0, uo.synthetic_state_dict(3))\n"
+            "x = np.concatenate([g['rand32_x'][:1].reshape(1, 32, 32)] * 2, axis=0)\n"
+            "lab, logp = eng.forward(0, x)\n"
+            "err = float(np.abs(logp[:1] - g['rand32_logp'][:1]).max()); print('ERR', err)\n"
+            "assert err < 1e-3 and np.array_equal(logp[0], logp[1])\n"
+            "np.save(sys.argv[1], logp)\n") % (os.path.dirname(here), golden_dir)
+    import tempfile
+
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        for k in ("0", "576"):
+            f = os.path.join(d, f"logp{k}.npy")
+            r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, LM_H3_KSPLIT_K=k, OMP_NUM_THREADS="8"), capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0, r.stdout + r.stderr
+            out[k] = np.load(f)
+    d = float(np.abs(out["0"] - out["576"]).max())
+    assert 0 < d < 2e-4, d  # (another summation order: not the same bits, the same numbers)

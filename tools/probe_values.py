@@ -25,4 +25,4 @@ models.append(("BatchNorm scales over 3 decades + heavy tails, head std 8", uo.c
 for name, sd in models:
     e.load_state_dict(0, sd)
     err, pinned = e.model_probe(0)
-    print(f"{name:62s} probe {err if err is None else format(err, '.2e')}  pinned {pinned}  runs on {e.model_precision(0)}", flush=True)
+    print(f"{name:62s} probe {err if err is None else format(err, '.2e')}  pinned {pinned}  runs on {e.model_tier(0)}", flush=True)
