@@ -348,7 +348,7 @@ def main():
                          "like production's for the 3-D post-processing), or the seeded random one of rounds 1-3")
     ap.add_argument("--post", default="auto", choices=["auto", "slab", "gathered"],
                     help="N>1 post-processing: slab-sharded, or label all-gather + redundant whole-volume pass; auto (default) = the pipeline's own "
-                         "choice by world size: slab from four ranks on (profiles/r05d_slab_timing_lunglike.log)")
+                         "choice by world size: slab from four ranks on (profiles/history/r05d_slab_timing_lunglike.log)")
     ap.add_argument("--dist", default="torch", choices=["torch", "native"],
                     help="N>1 collectives: torch.distributed (backend nccl = RCCL) or the engine's own RCCL communicator behind the C ABI (lm_dist_*)")
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2], help="forward lanes (2: consecutive batches overlap on two streams)")
@@ -507,6 +507,14 @@ def main():
         sampler = ChipSampler(local_rank, pci_bus_id=pci)
     if sampler is not None:
         sampler.start()
+    # The interpreter's cyclic garbage collector stays out of the measured passes: a generation-2 sweep over this process's object graph
+    # (torch is loaded) is a 40-55 ms pause that lands, deterministically for a given command line, wherever the allocation counter
+    # happens to run over -- round 6 found one inside the slab protocol's first stage of the breakdown step (profiles/r06y_*).  Collected
+    # once here, disabled until the measurements are over; nothing the steps do depends on it.
+    import gc
+
+    gc.collect()
+    gc.disable()
     # ---- the contract's timed region: exactly --steps steps between barrier + synchronise on both sides, max over ranks
     sync_all()
     t_first = t0 = time.perf_counter()
@@ -551,8 +559,8 @@ def main():
     if args.streams == 1:
         stats = stats or solo
     # N > 1 (and the forced world of one): where ONE step's time goes on the engine's stream -- sliced stages, every collective with
-    # the bytes a rank contributes, post-processing, un-crop, output assembly -- and the host's share of the slab protocol; HIP events
-    # on the engine's stream, maximum over the ranks per entry (every rank walks the same sequence of stages and exchanges)
+    # the bytes a rank contributes, post-processing, un-crop, output assembly -- and the host's share of the slab protocol; the host clock
+    # behind a stream synchronisation at every boundary, maximum over the ranks per entry (every rank walks the same sequence)
     dist_breakdown = None
     if use_dist:
         pipe.want_breakdown = True
@@ -566,8 +574,8 @@ def main():
             dist_breakdown["collectives"] = [{"name": c["name"], "bytes_per_rank": c["bytes_per_rank"], "ms": round(over_ranks(c["ms"]), 4)} for c in bd["collectives"]]
             dist_breakdown["collectives_ms"] = round(sum(c["ms"] for c in dist_breakdown["collectives"]), 4)  # (of the per-entry maxima)
             dist_breakdown["segments_rank0"] = bd.get("segments")
-            dist_breakdown["note"] = ("one extra untimed step: HIP events on the engine's stream (the stream the kernels AND the collectives are enqueued on), max over "
-                                      "ranks per entry; *_ms = stream time of the stage without its collectives; host_merge_ms = wall time inside lm_slab_step "
+            dist_breakdown["note"] = ("one extra untimed step with a stream synchronisation at every stage / collective boundary (host clock; the engine's stream is the one "
+                                      "kernels AND collectives are enqueued on), max over ranks per entry; *_ms = the stage without its collectives; host_merge_ms = wall time inside lm_slab_step "
                                       "(the slab protocol's table merges incl. their waits for device data; 0 in the gathered form)")
 
     # numpy in -> numpy out: what a caller of the drop-in sees (SURVEY.md section 8d defines the metric on a host volume).  Two forms,
@@ -655,6 +663,7 @@ def main():
                             "consecutive results, queue fill / drain outside the passes); reuse_output = LMInferer(reuse_output=True), one pageable array for every "
                             "call; new_pageable_array_per_call = np.empty per call with the results kept alive (what a fresh allocation costs)"})
 
+    gc.enable()
     if rank == 0:
         value = n_total * args.steps / dt
         h3 = args.precision == "split_f16"

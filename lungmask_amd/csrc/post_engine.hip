@@ -298,7 +298,7 @@ int postprocess(lm_engine* e, uint8_t* lab, int N, int H, int W, const int* spar
     // The boxes / pairs kernels need nothing of steps 2-3.  Running them on the second forward lane's stream (idle here) BESIDE
     // region_stats / boundary_records instead of behind the first read-back was built and measured: the four latency- and atomic-bound
     // kernels slow each other down by what the overlap saves (first read-back 0.78 -> 0.88 ms, whole pass 1.62 -> 1.66 ms,
-    // profiles/r05f_post_timing_side_stream_ab.log) -- off by default, LM_POST_SIDE=1 is the hook.
+    // profiles/history/r05f_post_timing_side_stream_ab.log) -- off by default, LM_POST_SIDE=1 is the hook.
     static const bool side_ok = [] { const char* v = getenv("LM_POST_SIDE"); return v && v[0] == '1'; }();
     hipStream_t side = (graph && side_ok && e->stream2 != nullptr) ? e->stream2 : s;
     if (side != s && !ws.side_fork) {

@@ -1079,7 +1079,7 @@ hipError_t diag_pairs(const uint8_t* lab, const int* ids, Dims d, unsigned long 
     if (nvox == 0) return hipSuccess;
     if (d.W % 4 == 0 && (reinterpret_cast<uintptr_t>(lab) & 3) == 0 && nvox < (size_t)0x7fffffff) {
         const size_t pieces = (size_t)d.N * d.H * ((d.W + 255) / 256);
-        // contiguous ranges of pieces per workgroup (the longer the range, the more voxels share a table), 2048 workgroups when the volume has them (1024: 0.27 instead of 0.17 ms for 12 % fewer pairs, profiles/r05e_bench.json)
+        // contiguous ranges of pieces per workgroup (the longer the range, the more voxels share a table), 2048 workgroups when the volume has them (1024: 0.27 instead of 0.17 ms for 12 % fewer pairs, profiles/history/r05e_bench.json)
         const unsigned ppb = (unsigned)std::max<size_t>((pieces + 2047) / 2048, 16);
         LM_LAUNCH(diag_pairs_rows_kernel, dim3((unsigned)((pieces + ppb - 1) / ppb)), dim3(TPB), 0, s, lab, ids, d, pairs, count_dev, cap, ppb);
     } else {

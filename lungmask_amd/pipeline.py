@@ -139,23 +139,23 @@ class _InProcessMember:
 
 
 class _Marks:
-    """Time stamps on the engine's stream (HIP events through torch when the pipeline runs on a GPU, the host clock otherwise):
-    `mark(name)` closes the segment `name` -- everything enqueued on the stream since the previous mark."""
+    """Time stamps of ONE diagnostic call (bench.py's dist_breakdown): `mark(name)` waits for the engine's stream and closes the
+    segment `name` -- everything since the previous mark, the host's share included (the slab protocol alternates host merges and
+    kernels) -- on the host clock.  The extra synchronisations only exist in this one diagnostic call.  (A 40-55 ms first
+    post-processing segment that round 6 chased through two forms of this class was the interpreter's garbage collector: bench.py
+    now keeps it off during the measured passes.)"""
 
     def __init__(self, stream, device):
-        self.stream, self.device = stream, device
-        self.names, self.events, self.extra = [], [], {}
+        import time
+
+        self.stream, self.device, self.clock = stream, device, time.perf_counter
+        self.names, self.stamps, self.extra = [], [], {}
         self._stamp()
 
     def _stamp(self):
         if self.stream is not None:
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record(self.stream)
-            self.events.append(ev)
-        else:
-            import time
-
-            self.events.append(time.perf_counter())
+            self.stream.synchronize()
+        self.stamps.append(self.clock())
 
     def mark(self, name: str):
         self.names.append(name)
@@ -165,11 +165,8 @@ class _Marks:
         self.extra[key] = self.extra.get(key, 0.0) + ms
 
     def segments(self):
-        """[(name, ms)] in stream order (waits for the stream)."""
-        if self.stream is not None:
-            self.events[-1].synchronize()
-            return [(n, float(self.events[i].elapsed_time(self.events[i + 1]))) for i, n in enumerate(self.names)]
-        return [(n, (self.events[i + 1] - self.events[i]) * 1e3) for i, n in enumerate(self.names)]
+        """[(name, ms)] in order."""
+        return [(n, (self.stamps[i + 1] - self.stamps[i]) * 1e3) for i, n in enumerate(self.names)]
 
 
 class ShardedPipeline:
@@ -193,7 +190,7 @@ class ShardedPipeline:
         self.rank = dist.get_rank() if dist is not None else 0
         # None: by world size.  The slab protocol's fixed part (six exchanges, three host table merges) only pays from four ranks
         # on -- below the crossover the redundant whole-volume pass on the gathered labels is cheaper (tools/slab_timing.py)
-        # (round 5, lung-like labels of ONE 300 w-slice volume, profiles/r05d_slab_timing_lunglike.log: whole-volume pass 2.7 / 5.0 / 9.1 ms
+        # (round 5, lung-like labels of ONE 300 w-slice volume, profiles/history/r05d_slab_timing_lunglike.log: whole-volume pass 2.7 / 5.0 / 9.1 ms
         # at 600 / 1200 / 2400 slices against 3.7 / 4.7 / 6.5 ms per rank for the protocol at 2 / 4 / 8 ranks: the crossover is at four)
         self.sharded_post = (self.world >= 4) if sharded_post is None else bool(sharded_post)
         self._buf = {}
@@ -273,6 +270,8 @@ class ShardedPipeline:
         # (the agreed table capacities are remembered per volume geometry: the fused mode runs the protocol at the network's
         # resolution and at full resolution within one volume)
         self._slab_key = (tuple(int(v) for v in lab_slab.shape[1:]), len(spare))
+        if self._marks is not None:
+            self._marks.mark("compute:before_slab_begin")
         with self._on_engine_stream():
             return self._postprocess_slab(lab_slab, z0, n_total, spare, skip_below)
 
@@ -282,6 +281,8 @@ class ShardedPipeline:
         sp = (C.c_int * max(len(spare), 1))(*[int(v) for v in spare])
         e.L.check(lib.lm_slab_begin(e.h, lab_slab.data_ptr(), n_r, h, w, self.rank, self.world, int(z0), int(n_total), sp, len(spare), int(skip_below)),
                   "lm_slab_begin")
+        if self._marks is not None:
+            self._marks.mark("compute:slab_begin")
         rnd = 0
         while True:
             n = int(lib.lm_slab_pending(e.h))

@@ -8,7 +8,7 @@ travels to the GPU box where `/root/reference` does not exist.
 
 Parity pin: `tests/golden/unet_*.npz` were produced by running the reference's
 own `resunet.UNet` class (imported from /root/reference) on the same seeded
-state_dict -- see `oracle/make_golden.py`; `tests/test_oracle_unet.py`
+state_dict -- see `oracle/make_golden.py`; `tests/test_oracle.py`
 checks this restatement against them.
 
 Floating point: the tolerance of the path is 1e-3 absolute on the

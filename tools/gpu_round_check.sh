@@ -15,6 +15,9 @@ python bench.py --steps 20 --warmup 5 2>gpurun_out/bench_err.log | tail -1 > gpu
 for c in 3 4; do python bench.py --config $c --steps 3 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_${TAG}_config$c.json; cut -c1-160 gpurun_out/bench_${TAG}_config$c.json; done
 LM_HOST_TIMING=1 python tools/host_boundary.py 2>&1 | grep -v amdgpu.ids | tail -4 > gpurun_out/host_boundary_$TAG.log; tail -1 gpurun_out/host_boundary_$TAG.log
 python tools/slab_timing.py 2>&1 | grep -v amdgpu.ids > gpurun_out/slab_timing_$TAG.log; tail -4 gpurun_out/slab_timing_$TAG.log
+python tools/probe_values.py 2>&1 | grep -v amdgpu.ids > gpurun_out/probe_values_$TAG.log; tail -3 gpurun_out/probe_values_$TAG.log
+LM_ASYNC_TIMING=0 python tools/async_probe.py 12 2>&1 | grep -v amdgpu.ids > gpurun_out/async_probe_$TAG.log; tail -3 gpurun_out/async_probe_$TAG.log
+python tools/stress.py 60 2>&1 | grep -v amdgpu.ids > gpurun_out/stress_$TAG.log; tail -2 gpurun_out/stress_$TAG.log
 python tools/nn_perf.py 20 5 split_f16 2>&1 | grep -v amdgpu.ids > gpurun_out/nn_perf_$TAG.log; head -1 gpurun_out/nn_perf_$TAG.log
 R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG/trace -- python $R/bench.py --streams 1 --steps 2 --warmup 1 --no-cpu-baseline --host-steps 0 > $R/gpurun_out/prof_${TAG}_bench.json 2>$R/gpurun_out/prof_$TAG.log

@@ -30,6 +30,19 @@ for i in range(max(10, reps // 3)):
         bad += 1; print("MISMATCH in LMInferer.apply repetition", i, int((r != ref).sum()), flush=True)
     if i % 7 == 0: keep = r  # (held results force other pool blocks)
 print(f"LMInferer.apply: {max(10, reps // 3)} repetitions, {bad} differing outputs, {time.time() - t0:.1f} s", flush=True)
+# the same volumes through the queue (apply_async: two host threads, copy-in / copy-back beside the hot path), results held and dropped at random
+t0 = time.time(); bad = 0; pend = []; held = []
+n_async = max(12, reps // 3)
+for i in range(n_async + 1):
+    if i < n_async:
+        pend.append(inf.apply_async(vol))
+    while len(pend) > (2 if i < n_async else 0):
+        r = pend.pop(0).result()
+        bad += zlib.crc32(r.tobytes()) != ref_crc
+        if i % 5 == 0: held.append(r)
+        if len(held) > 2: held.pop(0)
+print(f"LMInferer.apply_async: {n_async} queued volumes, {bad} differing outputs, {time.time() - t0:.1f} s", flush=True)
+del held
 # labels of the network (before post-processing) with one and two lanes, small and odd batch sizes
 xf = eng.preprocess(vol[:100])[1]
 x = eng.to_device(xf); lab = eng.empty((100, 256, 256), np.uint8)
