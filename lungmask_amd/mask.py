@@ -183,6 +183,7 @@ class AsyncResult:
         self._res = None
         self._exc = None
         self._wait = None  # waits for the copy-back; None once it is known to have arrived
+        self._keep = None  # the inferer, while the volume is queued (the queue's threads only hold a weak reference to it)
 
     def _finish(self):
         with self._lock:
@@ -209,7 +210,10 @@ class _AsyncPipe:
     def __init__(self, inferer):
         import queue
 
-        self.inf = inferer
+        # The two threads must not keep the inferer alive (they are GC roots for as long as they run): they hold a weak reference, a
+        # queued volume's handle holds the strong one until its result is enqueued, and a finalizer on the inferer ends the threads
+        # when it goes away without close().
+        self.inf_ref = weakref.ref(inferer)
         self.eng = inferer.engine
         self.eng.pipe_upload(0, None)  # streams and events exist before the two threads touch them
         self.jobs = {}
@@ -222,9 +226,16 @@ class _AsyncPipe:
                         threading.Thread(target=self._runner, name="lungmask_amd-run", daemon=True)]
         for t in self.threads:
             t.start()
+        weakref.finalize(inferer, _AsyncPipe._stop_threads, self.up_q, self.run_q).atexit = False
+
+    @staticmethod
+    def _stop_threads(up_q, run_q):
+        up_q.put(None)
+        run_q.put(None)
 
     def submit(self, vol: np.ndarray) -> AsyncResult:
         h = AsyncResult()
+        h._keep = self.inf_ref()
         job = dict(seq=self.seq, k=self.seq % 2, vol=vol, handle=h, uploaded=threading.Event(), computed=threading.Event(), error=None)
         self.seq += 1
         with self.idle:
@@ -256,13 +267,14 @@ class _AsyncPipe:
     def _runner(self):
         import time
 
-        inf, eng = self.inf, self.eng
+        eng = self.eng
         t_prev = time.perf_counter()
         while True:
             job = self.run_q.get()
             if job is None:
                 return
             h = job["handle"]
+            inf = h._keep
             try:
                 t0 = time.perf_counter()
                 job["uploaded"].wait()
@@ -291,6 +303,7 @@ class _AsyncPipe:
                 h._exc = exc
                 job["computed"].set()
             job["vol"] = None
+            h._keep = inf = None
             h._enqueued.set()
             with self.idle:
                 self.pending -= 1

@@ -216,3 +216,25 @@ def test_apply_async_propagates_a_failing_volume_and_carries_on():
     assert np.array_equal(hs[2].result(), (vols[2] % 7).astype(np.uint8)) and np.array_equal(hs[3].result(), (vols[3] % 7).astype(np.uint8))
     inf._async.flush()
     inf._async.close()
+
+
+def test_apply_async_threads_do_not_keep_the_inferer_alive():
+    """The queue's two host threads hold a weak reference to the inferer: an inferer that is dropped without close() is collected, and
+    its finalizer ends the threads (they would otherwise pin it, and through it the engine, for the life of the process)."""
+    import threading
+    import time
+    import weakref
+
+    eng = _FakePipeEngine()
+    inf = _fake_inferer(eng)
+    assert np.array_equal(inf.apply_async(np.full((2, 4, 4), 5, np.int16)).result(), np.full((2, 4, 4), 5, np.uint8))
+    pipe = inf._async
+    threads = list(pipe.threads)
+    assert all(t.is_alive() for t in threads)
+    ref = weakref.ref(inf)
+    del inf, pipe
+    gc.collect()
+    assert ref() is None, "the queue's threads must not pin the inferer"
+    for t in threads:
+        t.join(timeout=5)
+    assert not any(t.is_alive() for t in threads)
